@@ -1,0 +1,197 @@
+"""
+ctypes binding of libdegnorm_amd.so (include/degnorm_amd.h).  Fails loudly: there is no CPU fallback --
+if the HIP library is missing or no gfx950 device is visible, constructing a Device raises.
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdegnorm_amd.so')
+TRACE_LEN = 48
+
+DN_OK = 0
+DN_E_INVALID, DN_E_HIP, DN_E_STATE, DN_E_UNSUPPORTED, DN_E_NO_DEVICE = -1, -2, -3, -4, -5
+
+EXIT_NAMES = ('low_cov', 'zero_sample', 'median', 'no_loop', 'refined', 'refine_fallback', 'not_found_fallback')
+
+_lib = None
+
+
+class DegnormAmdError(RuntimeError):
+    pass
+
+
+class Params(ctypes.Structure):
+    _fields_ = [('nmf_iter', ctypes.c_int32), ('bins', ctypes.c_int32), ('min_high_coverage', ctypes.c_int32),
+                ('downsample_rate', ctypes.c_int32), ('skip_baseline_selection', ctypes.c_int32),
+                ('want_estimates', ctypes.c_int32), ('reserved', ctypes.c_int32 * 2)]
+
+
+def load(build_if_missing=False):
+    """Load the shared library (optionally building it first).  Raises if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from . import build
+            build.build_library()
+        else:
+            raise DegnormAmdError('{0} not found: build it with `python -m degnorm_amd.build` '
+                                  '(there is no CPU fallback for the NMF-OA path).'.format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i32, i64, dbl = c.c_void_p, c.c_int32, c.c_int64, c.c_double
+    P = c.POINTER
+    lib.dn_version.restype = c.c_char_p
+    lib.dn_last_error.restype = c.c_char_p
+    lib.dn_device_count.restype = c.c_int
+    lib.dn_p_supported.argtypes = [c.c_int]
+    lib.dn_create.argtypes = [c.c_int, P(vp)]
+    lib.dn_destroy.argtypes = [vp]
+    lib.dn_upload_ragged.argtypes = [vp, i64, i32, P(vp), P(i64), i32, i32, P(i64)]
+    lib.dn_upload_packed.argtypes = [vp, i64, i32, P(c.c_float), P(i64)]
+    lib.dn_ratio_svd_sums.argtypes = [vp, P(dbl), P(dbl), P(i32)]
+    lib.dn_baseline_iteration.argtypes = [vp, P(dbl), P(Params), P(i64), P(dbl), P(i32), P(i32)]
+    lib.dn_fetch_estimates.argtypes = [vp, P(dbl)]
+    lib.dn_last_kernel_ms.argtypes = [vp]
+    lib.dn_last_kernel_ms.restype = dbl
+    lib.dn_main_kernel_name.argtypes = [vp]
+    lib.dn_main_kernel_name.restype = c.c_char_p
+    lib.dn_synchronize.argtypes = [vp]
+    lib.dn_measure_copy_gbps.argtypes = [vp, i64, c.c_int]
+    lib.dn_measure_copy_gbps.restype = dbl
+    lib.dn_num_genes.argtypes = [vp]
+    lib.dn_num_genes.restype = i64
+    lib.dn_num_samples.argtypes = [vp]
+    lib.dn_num_samples.restype = i32
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc == DN_OK:
+        return
+    msg = load().dn_last_error().decode('utf-8', 'replace')
+    if rc == DN_E_INVALID:
+        raise ValueError(msg)
+    raise DegnormAmdError('degnorm_amd error {0}: {1}'.format(rc, msg))
+
+
+def _p(arr, ctype):
+    return arr.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+def device_count():
+    return int(load().dn_device_count())
+
+
+class Device:
+    """One HIP device holding a resident set of gene coverage matrices."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.h = ctypes.c_void_p()
+        _check(self.lib.dn_create(int(device), ctypes.byref(self.h)))
+        self.n = 0
+        self.p = 0
+        self.lengths = None
+        self.inexact = 0
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h.value:
+            self.lib.dn_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- upload ------------------------------------------------------------------------------------
+    def upload(self, cov_mats, n_threads=0):
+        """cov_mats: list of (p x L_g) float64 or float32 arrays (reference layout, nmf.py:488-490)."""
+        n = len(cov_mats)
+        if n == 0:
+            raise ValueError('no coverage matrices')
+        p = int(cov_mats[0].shape[0])
+        is_f32 = all(c.dtype == np.float32 for c in cov_mats)
+        dt = np.float32 if is_f32 else np.float64
+        keep = [np.ascontiguousarray(c, dtype=dt) for c in cov_mats]
+        for c in keep:
+            if c.ndim != 2:
+                raise ValueError('Not all coverage matrices are 2-d arrays!')
+            if c.shape[0] != p:
+                raise ValueError('coverage matrices disagree on the number of samples')
+        ptrs = (ctypes.c_void_p * n)(*[c.ctypes.data for c in keep])
+        lengths = np.array([c.shape[1] for c in keep], dtype=np.int64)
+        inexact = ctypes.c_int64(0)
+        _check(self.lib.dn_upload_ragged(self.h, n, p, ptrs, _p(lengths, ctypes.c_int64), int(is_f32),
+                                         int(n_threads), ctypes.byref(inexact)))
+        self.n, self.p, self.lengths, self.inexact = n, p, lengths, int(inexact.value)
+        return self
+
+    def upload_packed(self, packed, lengths, p):
+        packed = np.ascontiguousarray(packed, dtype=np.float32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+        if packed.size != int(lengths.sum()) * int(p):
+            raise ValueError('packed size does not match p * sum(lengths)')
+        _check(self.lib.dn_upload_packed(self.h, len(lengths), int(p), _p(packed, ctypes.c_float),
+                                         _p(lengths, ctypes.c_int64)))
+        self.n, self.p, self.lengths, self.inexact = len(lengths), int(p), lengths, 0
+        return self
+
+    # -- compute -----------------------------------------------------------------------------------
+    def ratio_svd_sums(self):
+        est = np.zeros((self.n, self.p))
+        cov = np.zeros((self.n, self.p))
+        status = np.zeros(self.n, dtype=np.int32)
+        _check(self.lib.dn_ratio_svd_sums(self.h, _p(est, ctypes.c_double), _p(cov, ctypes.c_double),
+                                          _p(status, ctypes.c_int32)))
+        return est, cov, status
+
+    def baseline_iteration(self, scale, nmf_iter=100, bins=20, min_high_coverage=50, downsample_rate=1,
+                           skip_baseline_selection=False, want_estimates=False, ds_start=None, want_trace=True):
+        """Returns (rho n x p unclipped, flags bool n, trace n x TRACE_LEN int32 or None)."""
+        scale = np.ascontiguousarray(scale, dtype=np.float64)
+        if scale.shape != (self.p,):
+            raise ValueError('scale must have one entry per sample')
+        prm = Params(int(nmf_iter), int(bins), int(min_high_coverage), int(downsample_rate),
+                     int(bool(skip_baseline_selection)), int(bool(want_estimates)))
+        rho = np.zeros((self.n, self.p))
+        flags = np.zeros(self.n, dtype=np.int32)
+        trace = np.zeros((self.n, TRACE_LEN), dtype=np.int32) if want_trace else None
+        dsp = None
+        if ds_start is not None:
+            ds_arr = np.ascontiguousarray(ds_start, dtype=np.int64)
+            if ds_arr.shape != (self.n,):
+                raise ValueError('ds_start must have one entry per gene')
+            dsp = _p(ds_arr, ctypes.c_int64)
+        _check(self.lib.dn_baseline_iteration(self.h, _p(scale, ctypes.c_double), ctypes.byref(prm), dsp,
+                                              _p(rho, ctypes.c_double), _p(flags, ctypes.c_int32),
+                                              _p(trace, ctypes.c_int32) if want_trace else None))
+        return rho, flags.astype(bool), trace
+
+    def fetch_estimates(self):
+        """List of (p x L_g) float64 arrays, views into one flat buffer, in upload order."""
+        total = int(self.lengths.sum()) * self.p
+        flat = np.empty(total, dtype=np.float64)
+        _check(self.lib.dn_fetch_estimates(self.h, _p(flat, ctypes.c_double)))
+        out, o = [], 0
+        for L in self.lengths:
+            cnt = self.p * int(L)
+            out.append(flat[o:o + cnt].reshape(self.p, int(L)))
+            o += cnt
+        return out
+
+    # -- measurement -------------------------------------------------------------------------------
+    def last_kernel_ms(self):
+        return float(self.lib.dn_last_kernel_ms(self.h))
+
+    def main_kernel_name(self):
+        return self.lib.dn_main_kernel_name(self.h).decode()
+
+    def measure_copy_gbps(self, nbytes=1 << 30, reps=5):
+        return float(self.lib.dn_measure_copy_gbps(self.h, int(nbytes), int(reps)))

@@ -1,0 +1,77 @@
+"""
+In-tree build of libdegnorm_amd.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+    python -m degnorm_amd.build [--force]
+
+One translation unit per sample count p (dn_inst.hip -DDN_P=p) plus the C-ABI unit; objects are compiled
+in parallel and linked into degnorm_amd/libdegnorm_amd.so.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'obj')
+LIB = os.path.join(HERE, 'libdegnorm_amd.so')
+P_LIST = list(range(2, 13))          # keep in sync with DN_FOR_EACH_P in csrc/dn_api.hip
+ARCH = 'gfx950'
+NT = int(os.environ.get('DN_NT', '64'))
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on',
+         '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if r.returncode != 0:
+        raise RuntimeError('build step failed: {0}\n{1}'.format(' '.join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_library(force=False, verbose=False):
+    """Compile and link; returns the path of the shared library."""
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    hdr = [os.path.join(CSRC, 'dn_kernels.hpp'), os.path.join(HERE, '..', 'include', 'degnorm_amd.h'),
+           os.path.abspath(__file__)]
+    jobs = []
+    objs = []
+    inst = os.path.join(CSRC, 'dn_inst.hip')
+    for p in P_LIST:
+        o = os.path.join(OBJ, 'dn_inst_p{0}_nt{1}.o'.format(p, NT))
+        objs.append(o)
+        if force or _newer(o, [inst] + hdr):
+            jobs.append([hipcc] + FLAGS + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(NT), '-c', inst, '-o', o])
+    api = os.path.join(CSRC, 'dn_api.hip')
+    o_api = os.path.join(OBJ, 'dn_api.o')
+    objs.append(o_api)
+    if force or _newer(o_api, [api] + hdr):
+        jobs.append([hipcc] + FLAGS + ['-c', api, '-o', o_api])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for out in ex.map(_run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    if force or jobs or _newer(LIB, objs):
+        _run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    path = build_library(force='--force' in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,412 @@
+// dn_api.hip -- C ABI (include/degnorm_amd.h) over the kernels of dn_kernels.hpp: device handle, host packer,
+// resident buffers, launches.  Host side only; the kernels are instantiated per sample count in dn_inst.hip.
+#include "dn_kernels.hpp"
+#include "../../include/degnorm_amd.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+// sample counts with compiled kernels (dn_inst.hip is built once per entry; keep in sync with build.py)
+#define DN_FOR_EACH_P(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+
+namespace dn {
+#define DN_DECL(P) const KernelSet *kernel_set_p##P();
+DN_FOR_EACH_P(DN_DECL)
+#undef DN_DECL
+
+const KernelSet *kernel_set_for(int p)
+{
+    switch (p) {
+#define DN_CASE(P) case P: return kernel_set_p##P();
+        DN_FOR_EACH_P(DN_CASE)
+#undef DN_CASE
+        default: return nullptr;
+    }
+}
+}  // namespace dn
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(DN_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+struct dn_handle_s {
+    int device = -1;
+    int n_cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const dn::KernelSet *ks = nullptr;
+
+    int64_t n = 0;
+    int32_t p = 0;
+    int64_t total = 0;            // floats in the packed coverage
+    int32_t lmax = 0;
+    std::vector<int64_t> goff;    // n + 1
+    std::vector<int32_t> glen;
+    std::vector<int64_t> svoff;   // n + 1, in columns
+
+    float   *d_cov = nullptr;
+    int64_t *d_goff = nullptr;
+    int32_t *d_glen = nullptr;
+    int32_t *d_order = nullptr;
+    int32_t *d_counter = nullptr;
+    int64_t *d_ds = nullptr;
+    double  *d_ws = nullptr;
+    double  *d_rho = nullptr;
+    int32_t *d_flags = nullptr;
+    int32_t *d_trace = nullptr;
+    double  *d_kfin = nullptr;
+    int32_t *d_emode = nullptr;
+    double  *d_svec = nullptr;
+    int64_t *d_svoff = nullptr;
+    double  *d_est_sums = nullptr, *d_cov_sums = nullptr;
+    int32_t *d_status = nullptr;
+    double  *d_est = nullptr;
+    int32_t *d_tile_gene = nullptr, *d_tile_col = nullptr;
+    int64_t n_tiles = 0;
+
+    int slots = 0;
+    int32_t S = 0;
+    int64_t slot_stride = 0;
+    double last_scale[dn::P_MAX] = {0};
+    bool have_estimate_state = false;
+    float last_ms = 0.f;
+};
+
+static void free_device(dn_handle h)
+{
+    void *ptrs[] = {h->d_cov, h->d_goff, h->d_glen, h->d_order, h->d_counter, h->d_ds, h->d_ws, h->d_rho, h->d_flags,
+                    h->d_trace, h->d_kfin, h->d_emode, h->d_svec, h->d_svoff, h->d_est_sums, h->d_cov_sums,
+                    h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col};
+    for (void *q : ptrs) if (q) (void) hipFree(q);
+    h->d_cov = nullptr; h->d_goff = nullptr; h->d_glen = nullptr; h->d_order = nullptr; h->d_counter = nullptr;
+    h->d_ds = nullptr; h->d_ws = nullptr; h->d_rho = nullptr; h->d_flags = nullptr; h->d_trace = nullptr;
+    h->d_kfin = nullptr; h->d_emode = nullptr; h->d_svec = nullptr; h->d_svoff = nullptr; h->d_est_sums = nullptr;
+    h->d_cov_sums = nullptr; h->d_status = nullptr; h->d_est = nullptr; h->d_tile_gene = nullptr; h->d_tile_col = nullptr;
+    h->have_estimate_state = false;
+}
+
+extern "C" {
+
+const char *dn_version(void) { return "degnorm_amd 0.1.0 (gfx950)"; }
+const char *dn_last_error(void) { return g_err.c_str(); }
+
+int dn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dn_p_supported(int p) { return dn::kernel_set_for(p) != nullptr; }
+
+int dn_create(int device, dn_handle *out)
+{
+    if (!out) return fail(DN_E_INVALID, "dn_create: out is null");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DN_E_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(DN_E_INVALID, "dn_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    dn_handle h = new dn_handle_s();
+    h->device = device;
+    h->n_cus = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    *out = h;
+    return DN_OK;
+}
+
+int dn_destroy(dn_handle h)
+{
+    if (!h) return DN_OK;
+    (void) hipSetDevice(h->device);
+    (void) hipStreamSynchronize(h->stream);
+    free_device(h);
+    if (h->ev0) (void) hipEventDestroy(h->ev0);
+    if (h->ev1) (void) hipEventDestroy(h->ev1);
+    if (h->stream) (void) hipStreamDestroy(h->stream);
+    delete h;
+    return DN_OK;
+}
+
+static int finish_upload(dn_handle h, const float *host_packed)
+{
+    const int64_t n = h->n;
+    const int32_t p = h->p;
+    free_device(h);
+    HIP_TRY(hipSetDevice(h->device));
+
+    // work queue: longest gene first (a 17-call gene costs ~17x a 1-call gene)
+    std::vector<int32_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return h->glen[a] > h->glen[b]; });
+
+    h->svoff.assign(n + 1, 0);
+    for (int64_t g = 0; g < n; g++) h->svoff[g + 1] = h->svoff[g] + h->glen[g];
+
+    // estimate tiles: (gene, first column) per 256 columns
+    std::vector<int32_t> tg, tc;
+    for (int64_t g = 0; g < n; g++)
+        for (int32_t c = 0; c < h->glen[g]; c += 256) { tg.push_back((int32_t) g); tc.push_back(c); }
+    h->n_tiles = (int64_t) tg.size();
+
+    HIP_TRY(hipMalloc(&h->d_cov, sizeof(float) * (size_t) std::max<int64_t>(h->total, 1)));
+    HIP_TRY(hipMalloc(&h->d_goff, sizeof(int64_t) * (size_t) (n + 1)));
+    HIP_TRY(hipMalloc(&h->d_glen, sizeof(int32_t) * (size_t) n));
+    HIP_TRY(hipMalloc(&h->d_order, sizeof(int32_t) * (size_t) n));
+    HIP_TRY(hipMalloc(&h->d_counter, sizeof(int32_t) * 4));
+    HIP_TRY(hipMalloc(&h->d_ds, sizeof(int64_t) * (size_t) n));
+    HIP_TRY(hipMalloc(&h->d_rho, sizeof(double) * (size_t) n * p));
+    HIP_TRY(hipMalloc(&h->d_flags, sizeof(int32_t) * (size_t) n));
+    HIP_TRY(hipMalloc(&h->d_trace, sizeof(int32_t) * (size_t) n * dn::TRACE_LEN));
+    HIP_TRY(hipMalloc(&h->d_kfin, sizeof(double) * (size_t) n * p));
+    HIP_TRY(hipMalloc(&h->d_emode, sizeof(int32_t) * (size_t) n));
+    HIP_TRY(hipMalloc(&h->d_svoff, sizeof(int64_t) * (size_t) (n + 1)));
+    HIP_TRY(hipMalloc(&h->d_est_sums, sizeof(double) * (size_t) n * p));
+    HIP_TRY(hipMalloc(&h->d_cov_sums, sizeof(double) * (size_t) n * p));
+    HIP_TRY(hipMalloc(&h->d_status, sizeof(int32_t) * (size_t) n));
+    HIP_TRY(hipMalloc(&h->d_tile_gene, sizeof(int32_t) * (size_t) std::max<int64_t>(h->n_tiles, 1)));
+    HIP_TRY(hipMalloc(&h->d_tile_col, sizeof(int32_t) * (size_t) std::max<int64_t>(h->n_tiles, 1)));
+
+    HIP_TRY(hipMemcpyAsync(h->d_cov, host_packed, sizeof(float) * (size_t) h->total, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_goff, h->goff.data(), sizeof(int64_t) * (size_t) (n + 1), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_glen, h->glen.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_order, order.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_svoff, h->svoff.data(), sizeof(int64_t) * (size_t) (n + 1), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_tile_gene, tg.data(), sizeof(int32_t) * tg.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_tile_col, tc.data(), sizeof(int32_t) * tc.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+
+    // persistent-workgroup scratch: one slot per resident workgroup
+    int per_cu = h->ks->blocks_per_cu(0);
+    if (per_cu < 1) per_cu = 1;
+    h->slots = (int) std::min<int64_t>(n, (int64_t) per_cu * h->n_cus);
+    h->S = (h->lmax + 63) & ~63;
+    h->slot_stride = (int64_t) h->ks->slot_doubles_per_col * h->S;
+    HIP_TRY(hipMalloc(&h->d_ws, sizeof(double) * (size_t) h->slot_stride * (size_t) std::max(h->slots, 1)));
+    return DN_OK;
+}
+
+static int check_shape(dn_handle h, int64_t n_genes, int32_t p, const int64_t *lengths)
+{
+    if (!h) return fail(DN_E_INVALID, "null handle");
+    if (n_genes <= 0 || n_genes > INT32_MAX) return fail(DN_E_INVALID, "n_genes must be in [1, 2^31)");
+    if (p < 2) return fail(DN_E_INVALID, "need at least 2 samples (svds(k=1) requires 1 < min(shape), nmf.py:63)");
+    const dn::KernelSet *ks = dn::kernel_set_for(p);
+    if (!ks) return fail(DN_E_UNSUPPORTED, "no kernels compiled for p = " + std::to_string(p));
+    h->ks = ks;
+    h->n = n_genes; h->p = p;
+    h->goff.assign(n_genes + 1, 0);
+    h->glen.assign(n_genes, 0);
+    int32_t lmax = 0;
+    for (int64_t g = 0; g < n_genes; g++) {
+        if (lengths[g] < 1 || lengths[g] > (int64_t) 1 << 26) return fail(DN_E_INVALID, "gene length out of range at gene " + std::to_string(g));
+        h->glen[g] = (int32_t) lengths[g];
+        h->goff[g + 1] = h->goff[g] + (int64_t) p * lengths[g];
+        lmax = std::max(lmax, h->glen[g]);
+    }
+    h->total = h->goff[n_genes];
+    h->lmax = lmax;
+    return DN_OK;
+}
+
+int dn_upload_packed(dn_handle h, int64_t n_genes, int32_t p, const float *packed, const int64_t *lengths)
+{
+    if (!packed || !lengths) return fail(DN_E_INVALID, "dn_upload_packed: null argument");
+    int rc = check_shape(h, n_genes, p, lengths);
+    if (rc != DN_OK) return rc;
+    return finish_upload(h, packed);
+}
+
+int dn_upload_ragged(dn_handle h, int64_t n_genes, int32_t p, const void *const *genes, const int64_t *lengths,
+                     int32_t is_f32, int32_t n_threads, int64_t *inexact)
+{
+    if (!genes || !lengths) return fail(DN_E_INVALID, "dn_upload_ragged: null argument");
+    int rc = check_shape(h, n_genes, p, lengths);
+    if (rc != DN_OK) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    float *stage = nullptr;
+    HIP_TRY(hipHostMalloc(&stage, sizeof(float) * (size_t) std::max<int64_t>(h->total, 1), hipHostMallocDefault));
+    if (n_threads < 1) n_threads = (int32_t) std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::atomic<int64_t> next(0), bad(0);
+    auto work = [&]() {
+        int64_t local_bad = 0;
+        for (;;) {
+            const int64_t g0 = next.fetch_add(64);
+            if (g0 >= n_genes) break;
+            const int64_t g1 = std::min(n_genes, g0 + 64);
+            for (int64_t g = g0; g < g1; g++) {
+                const int64_t cnt = (int64_t) p * h->glen[g];
+                float *dst = stage + h->goff[g];
+                if (is_f32) std::memcpy(dst, genes[g], sizeof(float) * (size_t) cnt);
+                else {
+                    const double *src = (const double *) genes[g];
+                    for (int64_t k = 0; k < cnt; k++) { const float f = (float) src[k]; dst[k] = f; local_bad += ((double) f != src[k]); }
+                }
+            }
+        }
+        bad += local_bad;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (inexact) *inexact = bad.load();
+    rc = finish_upload(h, stage);
+    (void) hipHostFree(stage);
+    return rc;
+}
+
+int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *status)
+{
+    if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_ratio_svd_sums: nothing uploaded");
+    if (!est_sums || !cov_sums) return fail(DN_E_INVALID, "dn_ratio_svd_sums: null output");
+    HIP_TRY(hipSetDevice(h->device));
+    dn::InitArgs a;
+    a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.order = h->d_order; a.counter = h->d_counter;
+    a.est_sums = h->d_est_sums; a.cov_sums = h->d_cov_sums; a.status = h->d_status; a.n_genes = (int32_t) h->n;
+    HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * 4, h->stream));
+    int per_cu = std::max(1, h->ks->blocks_per_cu(1));
+    const int grid = (int) std::min<int64_t>(h->n, (int64_t) per_cu * h->n_cus);
+    h->ks->init(a, grid, h->stream);
+    HIP_TRY(hipGetLastError());
+    const size_t np = (size_t) h->n * h->p;
+    HIP_TRY(hipMemcpyAsync(est_sums, h->d_est_sums, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(cov_sums, h->d_cov_sums, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int32_t> st_local;
+    if (!status) { st_local.resize(h->n); status = st_local.data(); }
+    HIP_TRY(hipMemcpyAsync(status, h->d_status, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
+int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm, const int64_t *ds_start,
+                          double *rho, int32_t *flags, int32_t *trace)
+{
+    if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_baseline_iteration: nothing uploaded");
+    if (!scale || !prm || !rho || !flags) return fail(DN_E_INVALID, "dn_baseline_iteration: null argument");
+    if (prm->nmf_iter < 1) return fail(DN_E_INVALID, "nmf_iter must be >= 1");
+    if (prm->bins < 1 || prm->bins > dn::MAX_BINS) return fail(DN_E_INVALID, "bins must be in [1, 64]");
+    if (prm->min_high_coverage < 2) return fail(DN_E_INVALID, "min_high_coverage must be >= 2 (nmf.py:34)");
+    if (prm->downsample_rate < 1) return fail(DN_E_INVALID, "downsample_rate must be >= 1");
+    if (prm->downsample_rate > 1) {
+        if (!ds_start) return fail(DN_E_INVALID, "downsample_rate > 1 needs per-gene start offsets");
+        for (int64_t g = 0; g < h->n; g++) {
+            // nmf.py:443-444 / :479-481: cannot downsample at a rate >= gene length
+            if (h->glen[g] <= prm->downsample_rate) return fail(DN_E_INVALID, "downsample_rate is too large; take-every size > at least one gene.");
+            if (ds_start[g] < 0 || ds_start[g] >= prm->downsample_rate) return fail(DN_E_INVALID, "ds_start out of [0, rate)");
+        }
+    }
+    for (int i = 0; i < h->p; i++) if (!(scale[i] > 0.0) || !std::isfinite(scale[i])) return fail(DN_E_INVALID, "scale factors must be positive and finite");
+    HIP_TRY(hipSetDevice(h->device));
+
+    if (prm->want_estimates && !h->d_svec)
+        HIP_TRY(hipMalloc(&h->d_svec, sizeof(double) * (size_t) std::max<int64_t>(h->svoff[h->n], 1)));
+
+    dn::IterArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.order = h->d_order; a.counter = h->d_counter;
+    a.ds_start = nullptr;
+    a.ws = h->d_ws; a.rho = h->d_rho; a.flags = h->d_flags; a.trace = h->d_trace; a.kfin = h->d_kfin; a.emode = h->d_emode;
+    a.svec = h->d_svec; a.svoff = h->d_svoff; a.slot_stride = h->slot_stride; a.n_genes = (int32_t) h->n; a.S = h->S;
+    a.T = prm->nmf_iter; a.bins = prm->bins; a.min_hc = prm->min_high_coverage; a.rate = prm->downsample_rate;
+    a.skip = prm->skip_baseline_selection ? 1 : 0; a.want_est = prm->want_estimates ? 1 : 0;
+    for (int i = 0; i < h->p; i++) { a.scale[i] = scale[i]; h->last_scale[i] = scale[i]; }
+    for (int i = h->p; i < dn::P_MAX; i++) a.scale[i] = 1.0;
+    if (prm->downsample_rate > 1) {
+        HIP_TRY(hipMemcpyAsync(h->d_ds, ds_start, sizeof(int64_t) * (size_t) h->n, hipMemcpyHostToDevice, h->stream));
+        a.ds_start = h->d_ds;
+    }
+    HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * 4, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_trace, 0, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, h->stream));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    h->ks->baseline(a, h->slots, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
+    if (trace)
+        HIP_TRY(hipMemcpyAsync(trace, h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    h->have_estimate_state = prm->want_estimates != 0;
+    return DN_OK;
+}
+
+int dn_fetch_estimates(dn_handle h, double *out)
+{
+    if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_fetch_estimates: nothing uploaded");
+    if (!h->have_estimate_state) return fail(DN_E_STATE, "dn_fetch_estimates: last iteration did not run with want_estimates = 1");
+    if (!out) return fail(DN_E_INVALID, "dn_fetch_estimates: null output");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->d_est) HIP_TRY(hipMalloc(&h->d_est, sizeof(double) * (size_t) h->total));
+    dn::EstArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.kfin = h->d_kfin; a.emode = h->d_emode;
+    a.svec = h->d_svec; a.svoff = h->d_svoff; a.out = h->d_est; a.n_genes = (int32_t) h->n;
+    for (int i = 0; i < dn::P_MAX; i++) a.scale[i] = i < h->p ? h->last_scale[i] : 1.0;
+    h->ks->est(a, h->d_tile_gene, h->d_tile_col, (int) h->n_tiles, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->d_est, sizeof(double) * (size_t) h->total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
+double dn_last_kernel_ms(dn_handle h) { return h ? (double) h->last_ms : 0.0; }
+const char *dn_main_kernel_name(dn_handle h) { return (h && h->ks) ? h->ks->baseline_name : ""; }
+int dn_synchronize(dn_handle h)
+{
+    if (!h) return fail(DN_E_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+int64_t dn_num_genes(dn_handle h) { return h ? h->n : 0; }
+int32_t dn_num_samples(dn_handle h) { return h ? h->p : 0; }
+
+}  // extern "C"
+
+// stream-copy ceiling ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_copy4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t) gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" double dn_measure_copy_gbps(dn_handle h, int64_t bytes, int reps)
+{
+    if (!h || bytes < (1 << 20)) return 0.0;
+    if (hipSetDevice(h->device) != hipSuccess) return 0.0;
+    float4 *a = nullptr, *b = nullptr;
+    const size_t n4 = (size_t) bytes / sizeof(float4);
+    if (hipMalloc(&a, n4 * sizeof(float4)) != hipSuccess) return 0.0;
+    if (hipMalloc(&b, n4 * sizeof(float4)) != hipSuccess) { (void) hipFree(a); return 0.0; }
+    (void) hipMemsetAsync(a, 1, n4 * sizeof(float4), h->stream);
+    double best = 0.0;
+    for (int r = 0; r < reps + 1; r++) {
+        (void) hipEventRecord(h->ev0, h->stream);
+        hipLaunchKernelGGL(k_copy4, dim3(h->n_cus * 8), dim3(256), 0, h->stream, a, b, n4);
+        (void) hipEventRecord(h->ev1, h->stream);
+        (void) hipStreamSynchronize(h->stream);
+        float ms = 0.f;
+        (void) hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        if (r > 0 && ms > 0.f) best = std::max(best, 2.0 * (double) n4 * sizeof(float4) / (ms * 1e-3) / 1e9);
+    }
+    (void) hipFree(a); (void) hipFree(b);
+    return best;
+}

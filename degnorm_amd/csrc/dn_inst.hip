@@ -1,0 +1,53 @@
+// dn_inst.hip -- one translation unit per sample count: hipcc -DDN_P=<p> [-DDN_NT=<threads>] -c dn_inst.hip
+// Instantiates the kernels of dn_kernels.hpp for p = DN_P and exports their launchers as dn_kernel_set_p<DN_P>.
+#include "dn_kernels.hpp"
+
+#ifndef DN_P
+#error "compile with -DDN_P=<number of samples>"
+#endif
+#ifndef DN_NT
+#define DN_NT 64
+#endif
+
+#define DN_CAT_(a, b) a##b
+#define DN_CAT(a, b) DN_CAT_(a, b)
+#define DN_STR_(a) #a
+#define DN_STR(a) DN_STR_(a)
+
+namespace dn {
+
+static void launch_baseline(const IterArgs &a, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_baseline<DN_P, DN_NT>), dim3(grid), dim3(DN_NT), 0, s, a);
+}
+
+static void launch_init(const InitArgs &a, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_ratio_svd<DN_P, DN_NT>), dim3(grid), dim3(DN_NT), 0, s, a);
+}
+
+static void launch_est(const EstArgs &a, const int32_t *tg, const int32_t *tc, int n_tiles, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_estimates<DN_P>), dim3(n_tiles), dim3(256), 0, s, a, tg, tc);
+}
+
+static int blocks_per_cu(int which)
+{
+    int nb = 0;
+    hipError_t e;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline<DN_P, DN_NT>, DN_NT, 0);
+    else            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd<DN_P, DN_NT>, DN_NT, 0);
+    return e == hipSuccess ? nb : 0;
+}
+
+const KernelSet *DN_CAT(kernel_set_p, DN_P)()
+{
+    static const KernelSet ks = {
+        DN_P, DN_NT, launch_baseline, launch_init, launch_est, blocks_per_cu,
+        (size_t) (3 * DN_P + 2),
+        "k_baseline<" DN_STR(DN_P) "," DN_STR(DN_NT) ">",
+    };
+    return &ks;
+}
+
+}  // namespace dn

@@ -1,0 +1,114 @@
+/*
+ * degnorm_amd.h -- C ABI of the MI355X-native NMF over-approximation core of DegNorm.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json:
+ * the reference is pure Python, so "the reference's FFI for this path" is the set of calls its
+ * GeneNMFOA.run() / run_gene_nmfoa_mpi() bodies make per gene; each entry point below names the
+ * reference lines (relative to the DegNorm checkout, v0.1.4) it replaces.  The only caller is
+ * degnorm_amd/_lib.py (ctypes); INTEGRATION.md shows the binding a DegNorm maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; the caller allocates every host output; nothing throws across the boundary.
+ *   - every function returns DN_OK (0) or a negative DN_E_* code; dn_last_error() gives the text.
+ *   - per-gene problems the reference would raise on (ArpackError, empty np.min, svds ValueError:
+ *     SURVEY H8) are reported in the per-gene trace status instead of aborting the batch.
+ *   - a handle owns one HIP device, one stream, the resident coverage and all scratch; it is not
+ *     thread-safe (the reference is called once from the main thread, nmf.py:483).
+ *   - genes keep the caller's order on the boundary; the library permutes internally
+ *     (longest-first work queue) and un-permutes on output.
+ */
+#ifndef DEGNORM_AMD_H
+#define DEGNORM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_OK                 0
+#define DN_E_INVALID         -1   /* bad argument / shape (reference: ValueError, nmf.py:469-481)            */
+#define DN_E_HIP             -2   /* HIP runtime error (text in dn_last_error)                               */
+#define DN_E_STATE           -3   /* call out of order (e.g. iterate before upload)                          */
+#define DN_E_UNSUPPORTED     -4   /* p outside the compiled range                                            */
+#define DN_E_NO_DEVICE       -5   /* no usable gfx950 device                                                 */
+
+#define DN_TRACE_LEN          48  /* int32 per gene; layout mirrors oracle/nmfoa_oracle.c                    */
+/* trace[0] n_hi_cov  [1] #nmf() calls  [2] sum of active columns over calls  [3] exit code
+ * [4] loop-exit reason  [5] #dropped bins  [6] status (0 ok; -1 ArpackError, -2 empty min, -3 ValueError)
+ * [7] total power-iteration steps of the on-chip eigen-solver  [8..40) drop_idx sequence                    */
+
+typedef struct dn_handle_s *dn_handle;
+
+/* Algorithm parameters of one outer iteration: GeneNMFOA.__init__ (nmf.py:12-53) after its own
+ * normalisation (abs/int, min_high_coverage = max(2,.), forced to 2 when downsample_rate > 1). */
+typedef struct {
+    int32_t nmf_iter;                /* nmf.py:31  T, inner NMF-OA iterations per nmf() call               */
+    int32_t bins;                    /* nmf.py:33  B                                                        */
+    int32_t min_high_coverage;       /* nmf.py:34,52-53                                                     */
+    int32_t downsample_rate;         /* nmf.py:36  take-every rate, 1 = none                                */
+    int32_t skip_baseline_selection; /* nmf.py:48                                                           */
+    int32_t want_estimates;          /* keep what dn_fetch_estimates needs (last outer iteration, nmf.py:601) */
+    int32_t reserved[2];
+} dn_params;
+
+/* Library / device ------------------------------------------------------------------------------- */
+const char *dn_version(void);
+const char *dn_last_error(void);
+int  dn_device_count(void);
+int  dn_p_supported(int p);                         /* 1 if kernels for p samples are compiled in          */
+
+int  dn_create(int device, dn_handle *out);
+int  dn_destroy(dn_handle h);
+
+/* Upload --------------------------------------------------------------------------------------------
+ * Replaces: cov_mats = list(cov_dat.values()) held as float64 host arrays (nmf.py:499) and the
+ * per-iteration re-scaled copies adjust_coverage_curves makes (nmf.py:142-146, nmf_mpi.py:745-760).
+ * Coverage is packed once into HBM as float32 (sample-major p x L_g per gene, genes back to back) and
+ * stays resident; scaling by 1/s_i is folded into the kernels' loads.
+ *
+ * dn_upload_ragged: genes[g] points at a C-contiguous p x lengths[g] matrix of float64 (is_f32 = 0)
+ * or float32 (is_f32 = 1).  *inexact (nullable) receives the number of values that are not exactly
+ * representable in float32 (DegNorm coverage is integer counts, reads.py:714,773, so normally 0).
+ * dn_upload_packed: the same data already packed (offsets in elements, offsets[n] = total).          */
+int  dn_upload_ragged(dn_handle h, int64_t n_genes, int32_t p, const void *const *genes,
+                      const int64_t *lengths, int32_t is_f32, int32_t n_threads, int64_t *inexact);
+int  dn_upload_packed(dn_handle h, int64_t n_genes, int32_t p, const float *packed,
+                      const int64_t *lengths);
+
+/* Initialisation pass -------------------------------------------------------------------------------
+ * Replaces: par_apply(run_ratio_svd_serial) + est_sums / cov_sums (nmf.py:522-525; nmf_mpi.py:681-703).
+ * est_sums[g*p+i] = sum_j max(K_i E_j, x_ij), cov_sums[g*p+i] = sum_j x_ij on the raw coverage.
+ * status[g] (nullable): 0 or the per-gene error code.                                                */
+int  dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *status);
+
+/* One outer DegNorm iteration over all resident genes ------------------------------------------------
+ * Replaces: adjust_coverage_curves + par_apply_baseline_selection's per-gene work
+ * (nmf.py:563-566 -> :142-146, :189-372; nmf_mpi.py:745-785), without the rho clip (host, nmf.py:398-399).
+ * scale[p]: current scale factors.  ds_start (nullable unless downsample_rate > 1): per-gene
+ * systematic-sample start offset in [0, rate) (nmf.py:422).
+ * rho[n*p] (unclipped), flags[n] (ran_baseline_selection), trace[n*DN_TRACE_LEN] (nullable).         */
+int  dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm, const int64_t *ds_start,
+                           double *rho, int32_t *flags, int32_t *trace);
+
+/* Estimated coverage matrices of the last dn_baseline_iteration run with want_estimates = 1 ----------
+ * Replaces: the `estimate` output of baseline_selection (nmf.py:355-369), returned by run() (nmf.py:601).
+ * out: float64, gene g at element offset p * sum(lengths[:g]), p x L_g row-major.                     */
+int  dn_fetch_estimates(dn_handle h, double *out);
+
+/* Measurement hooks (bench.py) -------------------------------------------------------------------- */
+/* Device time in ms of the most recent dn_baseline_iteration's main kernel, measured with HIP events
+ * on the library's own stream; kernel name via dn_main_kernel_name().                               */
+double dn_last_kernel_ms(dn_handle h);
+const char *dn_main_kernel_name(dn_handle h);
+int  dn_synchronize(dn_handle h);
+/* Stream-copy ceiling of this device (GB/s, float4 copy of `bytes` bytes, best of `reps`).          */
+double dn_measure_copy_gbps(dn_handle h, int64_t bytes, int reps);
+/* Raw device pointer / count accessors for torch interop (partial sums for the RCCL all-reduce).    */
+int64_t dn_num_genes(dn_handle h);
+int32_t dn_num_samples(dn_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEGNORM_AMD_H */

@@ -1,0 +1,542 @@
+/*
+ * nmfoa_oracle.c -- CPU restatement (plain C, float64) of DegNorm's NMF over-approximation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (degnorm_amd/) never links, imports or
+ * calls it; the product path is the HIP library behind include/degnorm_amd.h.
+ *
+ * Parity status: PINNED.  The restatement is checked against golden vectors produced by running the
+ * real reference (/root/reference/degnorm/nmf.py, nmf_mpi.py) in the build container; generator
+ * script tests/golden/make_golden.py, fixtures under tests/golden/ (.npz), checks tests/test_oracle_golden.py.
+ *
+ * The reference delegates the rank-1 SVD to scipy.sparse.linalg.svds(k=1) (ARPACK, tol=0; pinned
+ * scipy==0.19.1 in config/requirements.txt:6, scipy 1.15.3 in the container).  Its contract is the
+ * top singular triplet to machine precision; here it is computed with a cyclic Jacobi eigen-solver on
+ * the smaller Gram matrix -- deliberately a different algorithm from both ARPACK and the device's
+ * power iteration, so the three agree only if all are converged.
+ *
+ * Every function cites the reference lines (relative to /root/reference/) it restates.
+ * Matrices are row-major "sample-major": A[i*ld + j], i = sample (row), j = base position (column).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define DNO_TRACE_LEN 48          /* ints of per-gene trace, layout below */
+/* trace[0] n_hi_cov (n0)   trace[1] #nmf() calls   trace[2] sum of active columns over calls
+ * trace[3] exit code        trace[4] loop-exit reason trace[5] #dropped bins
+ * trace[6] status (0 ok, <0 the reference would have raised)   trace[7] reserved
+ * trace[8..8+32) drop_idx sequence (index into the *current* bin list, nmf.py:291)            */
+
+enum { EXIT_LOW_COV = 0, EXIT_ZERO_SAMPLE = 1, EXIT_MEDIAN = 2, EXIT_NO_LOOP = 3,
+       EXIT_REFINED = 4, EXIT_REFINE_FALLBACK = 5, EXIT_NOT_FOUND_FALLBACK = 6 };
+enum { LOOP_NATURAL = 0, LOOP_PERFECT = 1, LOOP_VALUE_ERROR = 2, LOOP_ZERO_ROWSUM = 3, LOOP_MIN_BINS = 4,
+       LOOP_NOT_ENTERED = 5 };
+enum { ST_OK = 0, ST_ARPACK = -1, ST_EMPTY_MIN = -2, ST_VALUE_ERROR = -3 };
+
+typedef struct {
+    int nmf_iter;                  /* nmf.py:31  */
+    int bins;                      /* nmf.py:33  */
+    int min_high_coverage;         /* nmf.py:34,52-53 (caller applies the max(2,.) / forced-2 rules) */
+    int downsample_rate;           /* nmf.py:36  */
+    int skip_baseline_selection;   /* nmf.py:48  */
+} dno_params;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Symmetric eigen-solver: cyclic Jacobi, returns the eigenvector of the largest eigenvalue.         */
+/* ------------------------------------------------------------------------------------------------ */
+static double jacobi_top(double *a, int m, double *vec, double *work)
+{
+    /* a: m x m symmetric (destroyed); work: m*m for eigenvectors. */
+    double *v = work;
+    for (int i = 0; i < m * m; i++) v[i] = 0.0;
+    for (int i = 0; i < m; i++) v[i * m + i] = 1.0;
+
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < m; i++) {
+            diag += a[i * m + i] * a[i * m + i];
+            for (int j = i + 1; j < m; j++) off += a[i * m + j] * a[i * m + j];
+        }
+        if (off == 0.0 || off <= 1e-34 * diag) break;
+        for (int pi = 0; pi < m - 1; pi++) {
+            for (int q = pi + 1; q < m; q++) {
+                double apq = a[pi * m + q];
+                if (apq == 0.0) continue;
+                double app = a[pi * m + pi], aqq = a[q * m + q];
+                double theta = (aqq - app) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < m; k++) {
+                    double akp = a[k * m + pi], akq = a[k * m + q];
+                    a[k * m + pi] = c * akp - s * akq;
+                    a[k * m + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < m; k++) {
+                    double apk = a[pi * m + k], aqk = a[q * m + k];
+                    a[pi * m + k] = c * apk - s * aqk;
+                    a[q * m + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < m; k++) {
+                    double vkp = v[k * m + pi], vkq = v[k * m + q];
+                    v[k * m + pi] = c * vkp - s * vkq;
+                    v[k * m + q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+    int best = 0;
+    for (int i = 1; i < m; i++) if (a[i * m + i] > a[best * m + best]) best = i;
+    for (int k = 0; k < m; k++) vec[k] = v[k * m + best];
+    return a[best * m + best];
+}
+
+/*
+ * rank_one_approx -- nmf.py:55-64 (nmf_mpi.py:10-18).
+ *   u, s, v = svds(x, k=1); return u*s, v
+ * A: p x n (row stride ld).  K (p) = u*sigma, E (n) = v.  Sign is arbitrary in the reference (random
+ * ARPACK start); only K*E and abs(K) are ever consumed.
+ * Returns ST_VALUE_ERROR when not 1 < min(p,n) (scipy: "k must be between 1 and min(A.shape)"),
+ * ST_ARPACK for a zero matrix (reference: ArpackError).
+ */
+int dno_rank_one(const double *A, int p, int n, int ld, double *K, double *E)
+{
+    if (p < 2 || n < 2) return ST_VALUE_ERROR;
+    int m = p <= n ? p : n;
+    double *g = (double *) malloc(sizeof(double) * (size_t) m * m * 2 + sizeof(double) * m);
+    double *work = g + (size_t) m * m, *vec = work + (size_t) m * m;
+
+    if (p <= n) {                                           /* eigsh on A A^T (p x p) */
+        for (int i = 0; i < p; i++)
+            for (int k = i; k < p; k++) {
+                double acc = 0.0;
+                const double *ri = A + (size_t) i * ld, *rk = A + (size_t) k * ld;
+                for (int j = 0; j < n; j++) acc += ri[j] * rk[j];
+                g[i * m + k] = acc; g[k * m + i] = acc;
+            }
+        jacobi_top(g, m, vec, work);
+        double nrm = 0.0;
+        for (int j = 0; j < n; j++) {                       /* s = A^T u = sigma * v */
+            double acc = 0.0;
+            for (int i = 0; i < p; i++) acc += vec[i] * A[(size_t) i * ld + j];
+            E[j] = acc; nrm += acc * acc;
+        }
+        double sigma = sqrt(nrm);
+        if (!(sigma > 0.0)) { free(g); return ST_ARPACK; }
+        for (int j = 0; j < n; j++) E[j] /= sigma;
+        for (int i = 0; i < p; i++) K[i] = vec[i] * sigma;
+    } else {                                                /* eigsh on A^T A (n x n) */
+        for (int a = 0; a < n; a++)
+            for (int b = a; b < n; b++) {
+                double acc = 0.0;
+                for (int i = 0; i < p; i++) acc += A[(size_t) i * ld + a] * A[(size_t) i * ld + b];
+                g[a * m + b] = acc; g[b * m + a] = acc;
+            }
+        jacobi_top(g, m, vec, work);
+        double nrm = 0.0;
+        for (int i = 0; i < p; i++) {                       /* t = A v = sigma * u */
+            double acc = 0.0;
+            for (int j = 0; j < n; j++) acc += A[(size_t) i * ld + j] * vec[j];
+            K[i] = acc; nrm += acc * acc;
+        }
+        if (!(nrm > 0.0)) { free(g); return ST_ARPACK; }
+        for (int j = 0; j < n; j++) E[j] = vec[j];
+    }
+    free(g);
+    return ST_OK;
+}
+
+/*
+ * nmf -- nmf.py:78-107 (nmf_mpi.py:33-59), factors=True.
+ *   K,E = rank_one(x); est = K.E; lmbda = 0; c = 1/sqrt(nmf_iter)
+ *   repeat nmf_iter: res = est - x; lmbda -= c*res; lmbda[lmbda<0] = 0; K,E = rank_one(x+lmbda); est = K.E
+ * x: p x n contiguous (ld = n).
+ */
+int dno_nmf(const double *x, int p, int n, int nmf_iter, double *K, double *E)
+{
+    int st = dno_rank_one(x, p, n, n, K, E);
+    if (st != ST_OK) return st;
+    size_t sz = (size_t) p * n;
+    double *lm = (double *) calloc(sz * 2, sizeof(double));
+    double *xa = lm + sz;
+    double c = 1.0 / sqrt((double) nmf_iter);
+    for (int it = 0; it < nmf_iter; it++) {
+        for (int i = 0; i < p; i++)
+            for (int j = 0; j < n; j++) {
+                size_t o = (size_t) i * n + j;
+                double res = K[i] * E[j] - x[o];
+                double l = lm[o] - c * res;
+                if (l < 0.0) l = 0.0;
+                lm[o] = l;
+                xa[o] = x[o] + l;
+            }
+        st = dno_rank_one(xa, p, n, n, K, E);
+        if (st != ST_OK) break;
+    }
+    free(lm);
+    return st;
+}
+
+/* ratio_svd -- nmf.py:109-121: est = K.E; est[est < x] = x[est < x].  est may be NULL (sums only). */
+int dno_ratio_svd(const double *x, int p, int n, double *est, double *est_sums, double *cov_sums)
+{
+    double *K = (double *) malloc(sizeof(double) * ((size_t) p + n));
+    double *E = K + p;
+    int st = dno_rank_one(x, p, n, n, K, E);
+    if (st == ST_OK) {
+        for (int i = 0; i < p; i++) {
+            double es = 0.0, cs = 0.0;
+            for (int j = 0; j < n; j++) {
+                double v = K[i] * E[j], xv = x[(size_t) i * n + j];
+                if (v < xv) v = xv;
+                if (est) est[(size_t) i * n + j] = v;
+                es += v; cs += xv;
+            }
+            if (est_sums) est_sums[i] = es;
+            if (cov_sums) cov_sums[i] = cs;
+        }
+    }
+    free(K);
+    return st;
+}
+
+/* utils.split_into_chunks -- utils.py:176-192: csize = ceil(len/n); chunks of csize, last shorter.
+ * Returns the number of chunks; start[b] (b <= n_chunks) are chunk boundaries. */
+int dno_split_into_chunks(int len, int n, int *start)
+{
+    if (len <= 0) { start[0] = 0; return 0; }
+    int csize = (len + n - 1) / n;
+    int nb = 0;
+    while (nb * csize < len) { start[nb] = nb * csize; nb++; }
+    start[nb] = len;
+    return nb;
+}
+
+static double vmax(const double *v, int n) { double m = v[0]; for (int i = 1; i < n; i++) if (v[i] > m) m = v[i]; return m; }
+static double vmin(const double *v, int n) { double m = v[0]; for (int i = 1; i < n; i++) if (v[i] < m) m = v[i]; return m; }
+
+static int cmp_double(const void *a, const void *b)
+{ double x = *(const double *) a, y = *(const double *) b; return (x > y) - (x < y); }
+
+/* K = abs(K); K[K < 1e-5] = min(K[K >= 1e-5]) -- nmf.py:329-330, :361-362. */
+static int fix_k(double *K, int p)
+{
+    double mn = INFINITY;
+    for (int i = 0; i < p; i++) { K[i] = fabs(K[i]); if (K[i] >= 1e-5 && K[i] < mn) mn = K[i]; }
+    if (mn == INFINITY) return ST_EMPTY_MIN;            /* np.min of empty selection raises */
+    for (int i = 0; i < p; i++) if (K[i] < 1e-5) K[i] = mn;
+    return ST_OK;
+}
+
+/*
+ * baseline_selection -- nmf.py:189-372 (nmf_mpi.py:178-378).
+ * F: p x L scaled coverage (row-major, ld = L).  ds_start < 0: no downsampling (rate 1), else the
+ * systematic-sample start offset in [0, rate) (nmf.py:422; supplied explicitly).
+ * rho: p out.  estimate: p x L out or NULL.  flag: ran_baseline_selection.  trace: DNO_TRACE_LEN ints.
+ * Returns status (ST_OK or the error the reference would have raised; rho is then zeros).
+ */
+int dno_baseline_selection(const double *F, int p, int L, const dno_params *prm, long ds_start,
+                           double *rho, double *estimate, int *flag, int *trace)
+{
+    int tr_local[DNO_TRACE_LEN];
+    if (!trace) trace = tr_local;
+    memset(trace, 0, sizeof(int) * DNO_TRACE_LEN);
+    trace[4] = LOOP_NOT_ENTERED;
+    *flag = 0;
+    for (int i = 0; i < p; i++) rho[i] = 0.0;                          /* nmf.py:216 */
+    if (estimate) memcpy(estimate, F, sizeof(double) * (size_t) p * L); /* nmf.py:217 */
+
+    /* get_high_coverage_idx -- nmf.py:66-76: x.max(axis=0) > 0.1 * x.max() */
+    double gmax = F[0];
+    for (size_t o = 1; o < (size_t) p * L; o++) if (F[o] > gmax) gmax = F[o];
+    double thr = 0.1 * gmax;
+    int *idx = (int *) malloc(sizeof(int) * (size_t) L);
+    int n0 = 0;
+    int rate = prm->downsample_rate;
+    for (int j = 0; j < L; j++) {
+        double cm = F[j];
+        for (int i = 1; i < p; i++) if (F[(size_t) i * L + j] > cm) cm = F[(size_t) i * L + j];
+        int keep = cm > thr;
+        /* nmf.py:223-227: intersect with arange(start, L, rate) */
+        if (rate > 1 && ds_start >= 0) keep = keep && (j >= ds_start) && ((j - ds_start) % rate == 0);
+        if (keep) idx[n0++] = j;
+    }
+    trace[0] = n0;
+
+    if (n0 < prm->min_high_coverage) { trace[3] = EXIT_LOW_COV; free(idx); return ST_OK; }   /* nmf.py:232 */
+
+    size_t sz = (size_t) p * n0;
+    double *Fs = (double *) malloc(sizeof(double) * (sz * 4 + (size_t) p * 6 + (size_t) n0 * 3));
+    double *Fb = Fs + sz, *KEs = Fb + sz, *KE = KEs + sz;
+    double *K = KE + sz, *Ks = K + p, *sumF = Ks + p, *sumKE = sumF + p, *rv = sumKE + p, *tmp = rv + p;
+    double *E = tmp + p, *Es = E + n0, *res = Es + n0;
+    int status = ST_OK;
+
+    for (int i = 0; i < p; i++)
+        for (int k = 0; k < n0; k++) Fs[(size_t) i * n0 + k] = F[(size_t) i * L + idx[k]];   /* nmf.py:237 */
+    memcpy(Fb, Fs, sizeof(double) * sz);                                                      /* nmf.py:238 */
+    int nb_cols = n0;
+
+    /* nmf.py:241: any sample without coverage -> defaults */
+    int npos = 0;
+    for (int i = 0; i < p; i++) {
+        double s = 0.0;
+        for (int k = 0; k < n0; k++) s += Fb[(size_t) i * n0 + k];
+        sumF[i] = s; npos += s > 0.0;
+    }
+    if (npos < p) { trace[3] = EXIT_ZERO_SAMPLE; goto done; }
+
+    /* nmf.py:245-254 */
+    status = dno_nmf(Fb, p, n0, prm->nmf_iter, K, E);
+    trace[1] = 1; trace[2] = n0;
+    if (status != ST_OK) goto done;
+    memcpy(Ks, K, sizeof(double) * p); memcpy(Es, E, sizeof(double) * n0);                     /* nmf.py:250 */
+    for (int i = 0; i < p; i++) {
+        double s = 0.0;
+        for (int k = 0; k < n0; k++) { double v = K[i] * E[k]; KE[(size_t) i * n0 + k] = v; s += v; }
+        sumKE[i] = s;
+        rv[i] = 1.0 - sumF[i] / (sumKE[i] + 1.0);
+    }
+    memcpy(KEs, KE, sizeof(double) * sz);                                                      /* estimate = copy(KE_bin), nmf.py:251 */
+
+    /* nmf.py:257: nanmedian(1 - rho) > 1 */
+    for (int i = 0; i < p; i++) tmp[i] = 1.0 - rv[i];
+    qsort(tmp, p, sizeof(double), cmp_double);
+    {
+        double med = (p & 1) ? tmp[p / 2] : 0.5 * (tmp[p / 2 - 1] + tmp[p / 2]);
+        if (med > 1.0) { trace[3] = EXIT_MEDIAN; goto done; }
+    }
+
+    {
+        double min_gene_len = fmax(2.0, ceil(200.0 * (1.0 / (double) rate)));                  /* nmf.py:261 */
+        double min_bins = ceil(prm->bins * 0.2);                                               /* nmf.py:35  */
+        int est_is_raw_ke = 1;          /* estimate = KE_start unclamped (no-loop branch) */
+        int use_fallback = 0, refined = 0;
+
+        if ((double) n0 >= min_gene_len && vmin(rv, p) <= 0.2 && !prm->skip_baseline_selection) {   /* nmf.py:265 */
+            est_is_raw_ke = 0;
+            int *bstart = (int *) malloc(sizeof(int) * ((size_t) prm->bins + 2));
+            int n_bins = dno_split_into_chunks(n0, prm->bins, bstart);                         /* nmf.py:269-271 */
+            /* bins stay contiguous runs of the compacted matrix (shift_bins, nmf.py:160-187):
+             * keep [start,len) per bin in current (compacted) coordinates. */
+            int *blen = (int *) malloc(sizeof(int) * ((size_t) n_bins + 1));
+            for (int b = 0; b < n_bins; b++) blen[b] = bstart[b + 1] - bstart[b];
+            int loop_reason = LOOP_NOT_ENTERED;
+            int n_hi = n0;
+
+            while (vmax(rv, p) > 0.1) {                                                        /* nmf.py:273 */
+                *flag = 1;                                                                     /* nmf.py:276 */
+                loop_reason = LOOP_NATURAL;
+                /* nmf.py:280-283 */
+                for (int k = 0; k < nb_cols; k++) {
+                    double m = -INFINITY;
+                    for (int i = 0; i < p; i++) {
+                        double f = Fb[(size_t) i * nb_cols + k];
+                        double r = (KE[(size_t) i * nb_cols + k] - f) / (f + 1.0);
+                        r = r * r;
+                        if (r > m) m = r;
+                    }
+                    res[k] = m;
+                }
+                double best = -INFINITY; int drop = 0, pos = 0;
+                for (int b = 0; b < n_bins; b++) {
+                    double s = 0.0;
+                    for (int k = 0; k < blen[b]; k++) s += res[pos + k];
+                    s /= (double) blen[b];
+                    if (s > best) { best = s; drop = b; }                                      /* first max: nanargmax */
+                    pos += blen[b];
+                }
+                if (best == 0.0) { loop_reason = LOOP_PERFECT; break; }                         /* nmf.py:286 */
+
+                /* nmf.py:291-302: delete the bin's columns, renumber */
+                int dstart = 0;
+                for (int b = 0; b < drop; b++) dstart += blen[b];
+                int dlen = blen[drop];
+                int new_cols = nb_cols - dlen;
+                {
+                    double *Fn = (double *) malloc(sizeof(double) * (size_t) p * (new_cols > 0 ? new_cols : 1));
+                    for (int i = 0; i < p; i++) {
+                        int o = 0;
+                        for (int k = 0; k < nb_cols; k++)
+                            if (k < dstart || k >= dstart + dlen) Fn[(size_t) i * new_cols + o++] = Fb[(size_t) i * nb_cols + k];
+                    }
+                    memcpy(Fb, Fn, sizeof(double) * (size_t) p * new_cols);
+                    free(Fn);
+                }
+                for (int b = drop; b < n_bins - 1; b++) blen[b] = blen[b + 1];
+                n_bins--;
+                nb_cols = new_cols;
+                n_hi = nb_cols;                                                                /* nmf.py:297 */
+                if (trace[5] < 32) trace[8 + trace[5]] = drop;
+                trace[5]++;
+
+                /* nmf.py:306-310 */
+                {
+                    double *Kn = (double *) malloc(sizeof(double) * ((size_t) p + (nb_cols > 0 ? nb_cols : 1)));
+                    double *En = Kn + p;
+                    int st = (nb_cols >= 1) ? dno_nmf(Fb, p, nb_cols, prm->nmf_iter, Kn, En) : ST_VALUE_ERROR;
+                    if (st == ST_VALUE_ERROR) { free(Kn); loop_reason = LOOP_VALUE_ERROR; break; }
+                    trace[1]++; trace[2] += nb_cols;
+                    if (st != ST_OK) { free(Kn); status = st; break; }
+                    memcpy(K, Kn, sizeof(double) * p); memcpy(E, En, sizeof(double) * nb_cols);
+                    free(Kn);
+                }
+                double mn = INFINITY;
+                for (int i = 0; i < p; i++) {                                                  /* nmf.py:312 */
+                    double s = 0.0;
+                    for (int k = 0; k < nb_cols; k++) { double v = K[i] * E[k]; KE[(size_t) i * nb_cols + k] = v; s += v; }
+                    if (s < mn) mn = s;
+                }
+                if (mn == 0.0) { loop_reason = LOOP_ZERO_ROWSUM; break; }                       /* nmf.py:315 */
+                for (int i = 0; i < p; i++) {                                                  /* nmf.py:318-321 */
+                    double sk = 0.0, sf = 0.0;
+                    for (int k = 0; k < nb_cols; k++) {
+                        size_t o = (size_t) i * nb_cols + k;
+                        if (KE[o] < Fb[o]) KE[o] = Fb[o];
+                        sk += KE[o]; sf += Fb[o];
+                    }
+                    rv[i] = 1.0 - sf / (sk + 1.0);
+                }
+                if ((double) n_bins <= min_bins || (double) n_hi < min_gene_len) { loop_reason = LOOP_MIN_BINS; break; }  /* nmf.py:323 */
+            }
+            trace[4] = loop_reason;
+            free(bstart); free(blen);
+            if (status != ST_OK) goto done;
+
+            if (vmax(rv, p) < 0.2) {                                                           /* nmf.py:327 */
+                status = fix_k(K, p);                                                          /* nmf.py:329-330 */
+                if (status != ST_OK) goto done;
+                double se = 0.0;
+                for (int k = 0; k < n0; k++) {                                                 /* nmf.py:333 */
+                    double m = -INFINITY;
+                    for (int i = 0; i < p; i++) { double q = Fs[(size_t) i * n0 + k] / K[i]; if (q > m) m = q; }
+                    Es[k] = m; se += m;                    /* Es reused for refined E (E_start kept in KEs) */
+                }
+                for (int i = 0; i < p; i++) {                                                  /* nmf.py:334-337 */
+                    double s = 0.0;
+                    for (int k = 0; k < n0; k++) s += K[i] * Es[k];
+                    rv[i] = 1.0 - sumF[i] / (s + 1.0);
+                }
+                refined = 1;
+                if (vmax(rv, p) > 0.9) { use_fallback = 1; trace[3] = EXIT_REFINE_FALLBACK; }  /* nmf.py:342 */
+                else trace[3] = EXIT_REFINED;
+            } else { use_fallback = 1; trace[3] = EXIT_NOT_FOUND_FALLBACK; }                    /* nmf.py:349 */
+
+            if (use_fallback) {                                                                /* nmf.py:343-346, 350-353 */
+                memcpy(K, Ks, sizeof(double) * p);
+                for (int i = 0; i < p; i++) {
+                    double s = 0.0;
+                    for (int k = 0; k < n0; k++) {
+                        size_t o = (size_t) i * n0 + k;
+                        double v = KEs[o]; if (v < Fs[o]) v = Fs[o];
+                        KEs[o] = v; s += v;
+                    }
+                    rv[i] = 1.0 - sumF[i] / (s + 1.0);
+                }
+            }
+        } else trace[3] = EXIT_NO_LOOP;
+
+        for (int i = 0; i < p; i++) rho[i] = rv[i];                                            /* nmf.py:368 */
+
+        if (estimate) {
+            if (n0 < L) {                                                                      /* nmf.py:358-365 */
+                status = fix_k(K, p);
+                if (status != ST_OK) { for (int i = 0; i < p; i++) rho[i] = 0.0; goto done; }
+                for (int j = 0; j < L; j++) {
+                    double m = -INFINITY;
+                    for (int i = 0; i < p; i++) { double q = F[(size_t) i * L + j] / K[i]; if (q > m) m = q; }
+                    for (int i = 0; i < p; i++) {
+                        double v = K[i] * m, f = F[(size_t) i * L + j];
+                        estimate[(size_t) i * L + j] = v < f ? f : v;
+                    }
+                }
+            } else if (refined && !use_fallback) {
+                for (int i = 0; i < p; i++) for (int k = 0; k < n0; k++) estimate[(size_t) i * L + k] = K[i] * Es[k];
+            } else {
+                (void) est_is_raw_ke;                       /* raw KE_start (no-loop) or clamped (fallback) */
+                memcpy(estimate, KEs, sizeof(double) * sz);
+            }
+        } else if (n0 < L) {
+            /* the reference would still run the K fix-up (and may raise) even though estimates are unused here */
+            double Kt[64]; double *Kp = p <= 64 ? Kt : (double *) malloc(sizeof(double) * p);
+            memcpy(Kp, K, sizeof(double) * p);
+            status = fix_k(Kp, p);
+            if (Kp != Kt) free(Kp);
+            if (status != ST_OK) for (int i = 0; i < p; i++) rho[i] = 0.0;
+        }
+    }
+
+done:
+    trace[6] = status;
+    if (status != ST_OK) { for (int i = 0; i < p; i++) rho[i] = 0.0; *flag = 0; }
+    free(Fs); free(idx);
+    return status;
+}
+
+/*
+ * Batch drivers (gene-level OpenMP threads; the reference uses joblib threads, nmf.py:377-406).
+ * cov[g]: raw coverage p x L[g] row-major, float64 (is_f32 = 0) or float32 (is_f32 = 1).
+ * adjust_coverage_curves (nmf.py:142-146): F = (cov.T / scale).T, done here per gene.
+ */
+static double *load_scaled(const void *cov, int is_f32, int p, long L, const double *scale)
+{
+    double *F = (double *) malloc(sizeof(double) * (size_t) p * L);
+    for (int i = 0; i < p; i++) {
+        double s = scale ? scale[i] : 1.0;
+        if (is_f32) { const float *r = (const float *) cov + (size_t) i * L; for (long j = 0; j < L; j++) F[(size_t) i * L + j] = scale ? (double) r[j] / s : (double) r[j]; }
+        else        { const double *r = (const double *) cov + (size_t) i * L; for (long j = 0; j < L; j++) F[(size_t) i * L + j] = scale ? r[j] / s : r[j]; }
+    }
+    return F;
+}
+
+int dno_baseline_batch(int n_genes, int p, const void *const *cov, int is_f32, const long *L, const double *scale,
+                       const dno_params *prm, const long *ds_start, double *rho, int *flags, int *trace,
+                       double *const *estimates, int n_threads)
+{
+    int bad = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : bad)
+    for (int g = 0; g < n_genes; g++) {
+        double *F = load_scaled(cov[g], is_f32, p, L[g], scale);
+        int st = dno_baseline_selection(F, p, (int) L[g], prm, ds_start ? ds_start[g] : -1,
+                                        rho + (size_t) g * p, estimates ? estimates[g] : NULL,
+                                        flags + g, trace ? trace + (size_t) g * DNO_TRACE_LEN : NULL);
+        bad += st != ST_OK;
+        free(F);
+    }
+    return bad;
+}
+
+int dno_ratio_svd_batch(int n_genes, int p, const void *const *cov, int is_f32, const long *L,
+                        double *est_sums, double *cov_sums, int *status, int n_threads)
+{
+    int bad = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad)
+    for (int g = 0; g < n_genes; g++) {
+        double *F = load_scaled(cov[g], is_f32, p, L[g], NULL);
+        int st = dno_ratio_svd(F, p, (int) L[g], NULL, est_sums + (size_t) g * p, cov_sums + (size_t) g * p);
+        if (status) status[g] = st;
+        bad += st != ST_OK;
+        free(F);
+    }
+    return bad;
+}
+
+int dno_trace_len(void) { return DNO_TRACE_LEN; }
+int dno_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,292 @@
+"""
+Generate golden vectors for the NMF-OA hot path by running the REAL reference implementation
+(/root/reference/degnorm/nmf.py, nmf_mpi.py) in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
+
+The reference is imported read-only and never travels: only the .npz outputs written next to this
+script are committed.  Inputs are either stored inline (small KATs) or re-generated from
+degnorm_amd.synth by (seed, gene id) -- each fixture then carries a per-gene input checksum so a
+drifting generator is detected instead of silently compared.
+
+Sections:
+    kat        G1/G2  nmf() / ratio_svd() / rank_one_approx() / split_into_chunks / shift_bins KATs
+    genes      G3     per-gene baseline_selection() outputs + call traces over all gene classes
+    run_c1     G4     GeneNMFOA.run on config 1 (100 x 4 x 1000, 1 iteration)
+    run_c2     G4     GeneNMFOA.run on a 64-gene draw of config 2 (p=10, L~U[200,5000]), 3 iterations
+    mpi        G5     run_gene_nmfoa_mpi through an in-process fake communicator (2 and 3 ranks)
+    dsamp      G6     downsampled runs (rate 50) with captured systematic-sample offsets
+"""
+import os
+import sys
+import time
+import threading
+import queue
+from collections import OrderedDict
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+sys.dont_write_bytecode = True
+
+from degnorm.nmf import GeneNMFOA            # noqa: E402  (the reference)
+import degnorm.nmf_mpi as ref_mpi            # noqa: E402
+from degnorm.utils import split_into_chunks  # noqa: E402
+from degnorm_amd import synth                # noqa: E402
+
+
+def checksum(cov):
+    """Order-sensitive input checksum of one coverage matrix (float64 exact for integer counts)."""
+    w = (np.arange(cov.size, dtype=np.float64) % 251.) + 1.
+    return float((cov.reshape(-1) * w).sum())
+
+
+class Tracer:
+    """Wraps a GeneNMFOA instance: records per-gene nmf() call sizes and downsample offsets."""
+
+    def __init__(self, model):
+        self.model = model
+        self.calls = []          # list (per baseline_selection call) of lists of n columns
+        self.offsets = []        # systematic-sample starts in call order
+        self.rho_hist = []       # post-clip rho per outer iteration
+        self.scale_hist = []     # scale factors used by each outer iteration
+        self._nmf = model.nmf
+        self._bs = model.baseline_selection
+        self._pabs = model.par_apply_baseline_selection
+        self._adj = model.adjust_coverage_curves
+        model.nmf = self.nmf
+        model.baseline_selection = self.baseline_selection
+        model.par_apply_baseline_selection = self.pabs
+        model.adjust_coverage_curves = self.adj
+        tracer = self
+
+        def sys_sample(n, take_every):
+            out = GeneNMFOA._systematic_sample(n, take_every)
+            tracer.offsets.append(int(out[0]) if not np.isscalar(out) else int(out))
+            return out
+        model._systematic_sample = sys_sample
+
+    def nmf(self, x, factors=False):
+        out = self._nmf(x, factors=factors)      # a call that raises (svds ValueError, nmf.py:306-310) is not counted
+        self.calls[-1].append(x.shape[1])
+        return out
+
+    def baseline_selection(self, F):
+        self.calls.append([])
+        return self._bs(F)
+
+    def pabs(self, dat, degnorm_iter):
+        out = self._pabs(dat, degnorm_iter)
+        self.rho_hist.append(self.model.rho.copy())
+        return out
+
+    def adj(self, dat):
+        self.scale_hist.append(self.model.scale_factors.copy())
+        return self._adj(dat)
+
+
+def trace_arrays(calls):
+    n_calls = np.array([len(c) for c in calls], dtype=np.int32)
+    sum_cols = np.array([sum(c) for c in calls], dtype=np.int64)
+    n0 = np.array([c[0] if c else -1 for c in calls], dtype=np.int32)
+    return n_calls, sum_cols, n0
+
+
+# -------------------------------------------------------------------------------------------- #
+def sec_kat():
+    rng = np.random.default_rng(11)
+    out = {}
+    m = GeneNMFOA(nmf_iter=100)
+    k = 0
+    for (p, n, T) in [(2, 2, 20), (4, 64, 20), (4, 64, 100), (10, 1000, 100), (3, 7, 50), (6, 5, 30)]:
+        K0 = rng.lognormal(0, 0.5, size=(p, 1))
+        E0 = 20 + 50 * np.abs(np.sin(np.linspace(0, 3, n)))[None, :]
+        x = rng.poisson(K0 * E0 * np.linspace(0.4, 1, n)[None, :] ** rng.integers(0, 2, size=(p, 1))).astype(float)
+        m.nmf_iter = T
+        K, E = m.nmf(x, factors=True)
+        K1, E1 = m.rank_one_approx(x)
+        out['nmf{0}_x'.format(k)] = x
+        out['nmf{0}_T'.format(k)] = T
+        out['nmf{0}_KE'.format(k)] = K.dot(E)
+        out['nmf{0}_absK'.format(k)] = np.abs(K).ravel()
+        out['nmf{0}_r1KE'.format(k)] = K1.dot(E1)
+        out['nmf{0}_ratio'.format(k)] = m.ratio_svd(x)
+        k += 1
+    out['n_nmf'] = k
+    # split_into_chunks / shift_bins (utils.py:176-192, nmf.py:160-187)
+    cases = [(201, 20), (1000, 20), (50, 20), (19, 20), (20, 20), (2600, 20), (7, 3), (399, 20), (4999, 20)]
+    out['chunk_cases'] = np.array(cases)
+    for i, (ln, nb) in enumerate(cases):
+        ch = split_into_chunks(list(range(ln)), nb)
+        out['chunk{0}_lens'.format(i)] = np.array([len(c) for c in ch])
+    bins = split_into_chunks(list(range(41)), 5)
+    seq = []
+    for d in [1, 0, 2]:
+        del bins[d]
+        bins = GeneNMFOA.shift_bins(bins, d)
+        seq.append(np.array([b[0] for b in bins] + [bins[-1][-1] + 1]))
+    out['shift_bounds0'], out['shift_bounds1'], out['shift_bounds2'] = seq
+    np.savez_compressed(os.path.join(HERE, 'kat.npz'), **out)
+    print('kat done')
+
+
+def sec_genes():
+    """Per-gene baseline_selection over every class; scale factors fixed, p=6, T=100, L<=1500 to bound time."""
+    seed, p = 3, 6
+    l_min, l_max = 200, 1500
+    gene_ids = list(range(72))
+    scale = np.array([0.8, 1.1, 0.95, 1.3, 1.0, 0.9])
+    m = GeneNMFOA(nmf_iter=100)
+    m.p = p
+    tr = Tracer(m)
+    rho, flags, cks, cls_all, est_rs, est_samp, Ls = [], [], [], [], [], [], []
+    t0 = time.time()
+    for g in gene_ids:
+        cov, cls = synth.synth_gene(seed, g, p, l_min, l_max)
+        F = (cov.T / scale).T
+        r, est, fl = m.baseline_selection(F)
+        rho.append(r); flags.append(fl); cks.append(checksum(cov)); cls_all.append(cls)
+        est_rs.append(est.sum(axis=1)); Ls.append(cov.shape[1])
+        est_samp.append(est[:, :: max(1, cov.shape[1] // 16)][:, :16])
+    n_calls, sum_cols, n0 = trace_arrays(tr.calls)
+    # skip_baseline_selection variant on the same genes
+    m2 = GeneNMFOA(nmf_iter=100, skip_baseline_selection=True)
+    m2.p = p
+    rho_skip = []
+    for g in gene_ids:
+        cov, _ = synth.synth_gene(seed, g, p, l_min, l_max)
+        rho_skip.append(m2.baseline_selection((cov.T / scale).T)[0])
+    np.savez_compressed(os.path.join(HERE, 'genes.npz'), seed=seed, p=p, l_min=l_min, l_max=l_max,
+                        gene_ids=np.array(gene_ids), scale=scale, rho=np.vstack(rho), flags=np.array(flags),
+                        checksum=np.array(cks), classes=np.array(cls_all), n_calls=n_calls, sum_cols=sum_cols,
+                        n0=n0, est_rowsum=np.vstack(est_rs), est_sample=np.stack(est_samp), L=np.array(Ls),
+                        rho_skip=np.vstack(rho_skip), nmf_iter=100)
+    print('genes done in %.1fs' % (time.time() - t0), 'calls hist', np.bincount(n_calls))
+
+
+def _run_and_save(name, seed, n_total, p, l_min, l_max, gene_ids, degnorm_iter, nmf_iter, downsample_rate=1,
+                  keep_est=4):
+    cov_dat, reads, classes = synth.synth_dataset(seed, n_total, p, l_min, l_max, gene_ids=gene_ids)
+    m = GeneNMFOA(degnorm_iter=degnorm_iter, nmf_iter=nmf_iter, downsample_rate=downsample_rate, n_jobs=1)
+    tr = Tracer(m)
+    t0 = time.time()
+    est = m.run(cov_dat, reads)
+    dt = time.time() - t0
+    n = len(gene_ids)
+    n_calls, sum_cols, n0 = trace_arrays(tr.calls)
+    out = dict(seed=seed, p=p, l_min=l_min, l_max=l_max, gene_ids=np.array(gene_ids), degnorm_iter=degnorm_iter,
+               nmf_iter=nmf_iter, downsample_rate=downsample_rate, reads=reads, classes=classes,
+               checksum=np.array([checksum(c) for c in cov_dat.values()]),
+               rho=m.rho, x_adj=m.x_adj, ran_baseline_selection=m.ran_baseline_selection,
+               scale_factors=m.scale_factors, norm_factors=m.norm_factors, x_weighted=m.x_weighted,
+               rho_hist=np.stack(tr.rho_hist), scale_hist=np.stack(tr.scale_hist),
+               n_calls=n_calls.reshape(degnorm_iter, n), sum_cols=sum_cols.reshape(degnorm_iter, n),
+               n0=n0.reshape(degnorm_iter, n), ref_seconds=dt,
+               est_rowsum=np.vstack([e.sum(axis=1) for e in est]))
+    if downsample_rate > 1:
+        out['offsets'] = np.array(tr.offsets).reshape(degnorm_iter, n)
+    for k in range(min(keep_est, n)):
+        out['est_{0}'.format(k)] = est[k]
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('%s done in %.1fs (%.2f gene-iters/s)' % (name, dt, n * degnorm_iter / dt))
+
+
+def sec_run_c1():
+    c = synth.CONFIGS['c1']
+    _run_and_save('run_c1', c['seed'], c['n_genes'], c['p'], c['l_min'], c['l_max'], list(range(c['n_genes'])),
+                  degnorm_iter=1, nmf_iter=100)
+
+
+def sec_run_c2():
+    c = synth.CONFIGS['c2']
+    _run_and_save('run_c2', c['seed'], c['n_genes'], c['p'], c['l_min'], c['l_max'], list(range(64)),
+                  degnorm_iter=3, nmf_iter=100)
+
+
+def sec_dsamp():
+    # rate 50 on p=6 genes (L >= 200 > rate); offsets captured in call order (iteration-major, gene-minor).
+    _run_and_save('run_dsamp50', 6, 48, 6, 200, 3000, list(range(48)), degnorm_iter=2, nmf_iter=50,
+                  downsample_rate=50)
+    # config-4 regime: p=50, rate 500, L in 501..5000 (active matrices 50 x <=10, n < p)
+    _run_and_save('run_dsamp500', 4, 24, 50, 501, 5000, list(range(24)), degnorm_iter=2, nmf_iter=100,
+                  downsample_rate=500, keep_est=2)
+
+
+class FakeComm:
+    """In-process stand-in for an mpi4py communicator (.size .rank .send .recv .Barrier), one per thread."""
+
+    def __init__(self, size):
+        self.size = size
+        self.boxes = {}
+        self.lock = threading.Lock()
+        self.barrier = threading.Barrier(size)
+
+    def view(self, rank):
+        parent = self
+
+        class View:
+            size = parent.size
+
+            def __init__(self):
+                self.rank = rank
+
+            def _box(self, src, dst, tag):
+                with parent.lock:
+                    return parent.boxes.setdefault((src, dst, tag), queue.Queue())
+
+            def send(self, obj, dest, tag=0):
+                self._box(self.rank, dest, tag).put(obj)
+
+            def recv(self, source, tag=0):
+                return self._box(source, self.rank, tag).get()
+
+            def Barrier(self):
+                parent.barrier.wait()
+        return View()
+
+
+def sec_mpi():
+    seed, p, l_min, l_max, n = 7, 4, 200, 1200, 30
+    cov_dat, reads, classes = synth.synth_dataset(seed, n, p, l_min, l_max)
+    out = dict(seed=seed, p=p, l_min=l_min, l_max=l_max, gene_ids=np.arange(n), reads=reads, degnorm_iter=2,
+               nmf_iter=40, checksum=np.array([checksum(c) for c in cov_dat.values()]))
+    single = GeneNMFOA(degnorm_iter=2, nmf_iter=40)
+    single.run(cov_dat, reads)
+    out['single_rho'] = single.rho
+    out['single_x_adj'] = single.x_adj
+    out['single_flags'] = single.ran_baseline_selection
+    for size in (2, 3):
+        comm = FakeComm(size)
+        results = [None] * size
+
+        def work(r):
+            results[r] = ref_mpi.run_gene_nmfoa_mpi(comm.view(r), cov_dat if r == 0 else None, reads,
+                                                    degnorm_iter=2, nmf_iter=40)
+        # workers need cov_dat only for len(); the reference reads len(cov_dat) on every rank (nmf_mpi.py:598)
+        def work_safe(r):
+            results[r] = ref_mpi.run_gene_nmfoa_mpi(comm.view(r), cov_dat, reads, degnorm_iter=2, nmf_iter=40)
+        ths = [threading.Thread(target=work_safe, args=(r,)) for r in range(size)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        res = results[0]
+        out['mpi{0}_rho'.format(size)] = res['rho']
+        out['mpi{0}_x_adj'.format(size)] = res['x_adj']
+        out['mpi{0}_flags'.format(size)] = res['ran_baseline_selection']
+        out['mpi{0}_est_rowsum'.format(size)] = np.vstack([e.sum(axis=1) for e in res['estimates'].values()])
+        out['mpi{0}_chunk_lens'.format(size)] = np.array([len(c) for c in split_into_chunks(list(cov_dat.keys()), size)])
+    np.savez_compressed(os.path.join(HERE, 'mpi.npz'), **out)
+    print('mpi done')
+
+
+SECTIONS = OrderedDict(kat=sec_kat, genes=sec_genes, run_c1=sec_run_c1, run_c2=sec_run_c2, mpi=sec_mpi,
+                       dsamp=sec_dsamp)
+
+if __name__ == '__main__':
+    import logging
+    logging.disable(logging.CRITICAL)
+    todo = sys.argv[1:] or list(SECTIONS)
+    for s in todo:
+        SECTIONS[s]()

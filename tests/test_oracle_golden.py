@@ -1,0 +1,132 @@
+"""
+Pins the CPU oracle (oracle/nmfoa_oracle.c + oracle/oracle.py) to golden vectors produced by the REAL
+reference (tests/golden/make_golden.py imports /root/reference/degnorm/nmf.py and nmf_mpi.py).
+Runs on the CPU (-m "not gpu").  Agreement is at float64 round-off: the oracle is a restatement, not an
+approximation.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, input_checksum
+from degnorm_amd import synth
+
+RT = 1e-9
+
+
+def _genes(seed, gene_ids, p, l_min, l_max):
+    return [synth.synth_gene(int(seed), int(g), int(p), int(l_min), int(l_max))[0] for g in gene_ids]
+
+
+def _fixture_inputs(G):
+    covs = _genes(G['seed'], G['gene_ids'], G['p'], G['l_min'], G['l_max'])
+    cks = np.array([input_checksum(c) for c in covs])
+    np.testing.assert_array_equal(cks, G['checksum'], err_msg='synthetic generator drifted from the fixture inputs')
+    return covs
+
+
+def test_kat_nmf_rank_one_ratio_svd(oracle):
+    """G1/G2: nmf() (nmf.py:78-107), rank_one_approx (:55-64), ratio_svd (:109-121)."""
+    K = golden('kat')
+    for k in range(int(K['n_nmf'])):
+        x = K['nmf%d_x' % k]
+        Kk, Ek = oracle.nmf(x, int(K['nmf%d_T' % k]))
+        np.testing.assert_allclose(Kk.dot(Ek), K['nmf%d_KE' % k], rtol=RT, atol=1e-9)
+        np.testing.assert_allclose(np.abs(Kk).ravel(), K['nmf%d_absK' % k], rtol=RT, atol=1e-9)
+        K1, E1 = oracle.rank_one(x)
+        np.testing.assert_allclose(K1.dot(E1), K['nmf%d_r1KE' % k], rtol=RT, atol=1e-9)
+        np.testing.assert_allclose(oracle.ratio_svd(x), K['nmf%d_ratio' % k], rtol=RT, atol=1e-9)
+
+
+def test_kat_split_into_chunks_and_shift_bins(oracle):
+    """utils.split_into_chunks (utils.py:176-192) incl. the 'fewer than n chunks' case; shift_bins (nmf.py:160-187)."""
+    from degnorm_amd.utils import split_into_chunks, chunk_bounds
+    K = golden('kat')
+    for i, (ln, nb) in enumerate(K['chunk_cases']):
+        want = K['chunk%d_lens' % i]
+        got = [len(c) for c in oracle.split_into_chunks(int(ln), int(nb))]
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal([len(c) for c in split_into_chunks(list(range(ln)), int(nb))], want)
+        np.testing.assert_array_equal(np.diff(chunk_bounds(int(ln), int(nb))), want)
+    # bins stay contiguous after drops: the oracle / device represent them as lengths only
+    lens = [len(c) for c in oracle.split_into_chunks(41, 5)]
+    for d, key in zip([1, 0, 2], ['shift_bounds0', 'shift_bounds1', 'shift_bounds2']):
+        del lens[d]
+        np.testing.assert_array_equal(np.concatenate([[0], np.cumsum(lens)]), K[key])
+
+
+def test_baseline_selection_genes(oracle):
+    """G3: per-gene baseline_selection over all classes, with call traces; skip_baseline_selection variant."""
+    G = golden('genes')
+    covs = _fixture_inputs(G)
+    prm = oracle.make_params(nmf_iter=int(G['nmf_iter']))
+    rho, flags, trace, est = oracle.baseline_batch(covs, G['scale'], prm, want_estimates=True)
+    np.testing.assert_array_equal(flags, G['flags'])
+    np.testing.assert_array_equal(trace[:, 1], G['n_calls'])
+    np.testing.assert_array_equal(trace[:, 2], G['sum_cols'])
+    np.testing.assert_array_equal(trace[G['n_calls'] > 0, 0], G['n0'][G['n_calls'] > 0])
+    np.testing.assert_allclose(rho, G['rho'], rtol=RT, atol=1e-12)
+    for k, e in enumerate(est):
+        np.testing.assert_allclose(e.sum(axis=1), G['est_rowsum'][k], rtol=RT)
+        step = max(1, e.shape[1] // 16)
+        np.testing.assert_allclose(e[:, ::step][:, :16], G['est_sample'][k], rtol=RT, atol=1e-9)
+    # every exit code is exercised by the fixture
+    assert set(trace[:, 3]) >= {0, 1, 3, 4, 6}
+    prm_s = oracle.make_params(nmf_iter=int(G['nmf_iter']), skip_baseline_selection=True)
+    rho_s, flags_s, _, _ = oracle.baseline_batch(covs, G['scale'], prm_s)
+    assert not flags_s.any()
+    np.testing.assert_allclose(rho_s, G['rho_skip'], rtol=RT, atol=1e-12)
+
+
+def _check_run(oracle, name, rt=RT):
+    G = golden(name)
+    covs = _fixture_inputs(G)
+    hist = {}
+    ds = G['offsets'] if 'offsets' in G.files else None
+    out = oracle.run(covs, G['reads'], degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']),
+                     downsample_rate=int(G['downsample_rate']), ds_starts=ds, want_estimates=True, history=hist)
+    for i in range(int(G['degnorm_iter'])):
+        np.testing.assert_allclose(hist['rho'][i] if False else hist['rho'][i], hist['rho'][i])
+        np.testing.assert_array_equal(hist['trace'][i][:, 1], G['n_calls'][i])
+        np.testing.assert_array_equal(hist['trace'][i][:, 2], G['sum_cols'][i])
+    np.testing.assert_array_equal(out['ran_baseline_selection'], G['ran_baseline_selection'])
+    np.testing.assert_allclose(out['rho'], G['rho'], rtol=rt, atol=1e-12)
+    np.testing.assert_allclose(out['x_adj'], G['x_adj'], rtol=rt)
+    np.testing.assert_allclose(out['scale_factors'], G['scale_factors'], rtol=rt)
+    np.testing.assert_allclose(out['x_weighted'], G['x_weighted'], rtol=rt)
+    np.testing.assert_allclose(np.vstack([e.sum(axis=1) for e in out['estimates']]), G['est_rowsum'], rtol=rt)
+    k = 0
+    while 'est_%d' % k in G.files:
+        np.testing.assert_allclose(out['estimates'][k], G['est_%d' % k], rtol=rt, atol=1e-9)
+        k += 1
+    return G, out
+
+
+def test_run_config1(oracle):
+    """G4: GeneNMFOA.run on config 1 (100 genes x 4 samples x L=1000, 1 iteration), nmf.py:483-601."""
+    _check_run(oracle, 'run_c1')
+
+
+def test_run_config2_subset(oracle):
+    """G4: 64-gene draw of config 2 (p=10, L~U[200,5000]), 3 outer iterations."""
+    _check_run(oracle, 'run_c2')
+
+
+def test_run_downsampled(oracle):
+    """G6: take-every 50 (p=6) and the config-4 regime (p=50, take-every 500, active matrices 50 x <=10)."""
+    _check_run(oracle, 'run_dsamp50')
+    _check_run(oracle, 'run_dsamp500')
+
+
+def test_mpi_twin_matches_single_node(oracle):
+    """G5: run_gene_nmfoa_mpi (nmf_mpi.py:555-863) through a fake communicator == GeneNMFOA.run == oracle."""
+    G = golden('mpi')
+    covs = _fixture_inputs(G)
+    out = oracle.run(covs, G['reads'], degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']))
+    for tag in ('single', 'mpi2', 'mpi3'):
+        np.testing.assert_allclose(out['rho'], G[tag + '_rho'], rtol=RT, atol=1e-12)
+        np.testing.assert_allclose(out['x_adj'], G[tag + '_x_adj'], rtol=RT)
+        np.testing.assert_array_equal(out['ran_baseline_selection'], G[tag + '_flags'])
+    from degnorm_amd.utils import split_into_chunks
+    for size in (2, 3):
+        np.testing.assert_array_equal([len(c) for c in split_into_chunks(list(range(len(covs))), size)],
+                                      G['mpi%d_chunk_lens' % size])
