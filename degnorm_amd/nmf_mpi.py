@@ -1,0 +1,306 @@
+"""
+Gene-sharded outer DegNorm iteration -- the MI355X counterpart of degnorm/nmf_mpi.py.
+
+The reference partitions genes over MPI ranks (nmf_mpi.py:603-629), has rank 0 re-scale and re-send every
+coverage matrix each iteration (:745-760) and collect every estimate and DI row (:796-815): ~GBs of pickle
+through rank 0 per iteration although the only cross-gene coupling is a length-p vector.  Here each rank
+(one process per GPU) uploads its contiguous gene chunk once, keeps it resident in HBM, and per outer
+iteration contributes 3p float64 partial sums to ONE all-reduce (RCCL over xGMI when the process group
+is "nccl"; gloo on CPU for tests):
+
+    A[i] = sum over genes with rho.max() > 0 of x_w[g,i] / (1 - rho[g,i])
+    B[i] = sum over genes with rho.max() == 0 of x_w[g,i]            (genes correct_di_scores rewrites)
+    W[i] = sum over all genes of x_w[g,i]
+
+from which every rank computes identically (nmf.py:148-158, :575-590; nmf_mpi.py:821-838):
+
+    S_pre = A + B;  avg_di = 1 - W / S_pre;  S_post = A + B * S_pre / W;
+    norm = S_post / median(S_post);  x_w /= norm;  scale *= norm
+
+`run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, ...)` keeps the reference's signature and return value
+(nmf_mpi.py:555-580, :852-863); `comm` may be a TorchComm (below) or any object with
+.size/.rank/.send/.recv/.Barrier (mpi4py duck type, as in the reference), optionally .allreduce.
+"""
+import logging
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from .utils import split_into_chunks
+from .results import write_results
+
+__all__ = ['run_gene_nmfoa_mpi', 'save_results', 'ShardedNMFOA', 'TorchComm', 'LocalComm']
+
+
+# ----------------------------------------------------------------------------------------------- #
+# communicators
+# ----------------------------------------------------------------------------------------------- #
+class LocalComm(object):
+    """Single-process communicator (size 1)."""
+    size = 1
+    rank = 0
+
+    def allreduce_sum(self, vec):
+        return np.array(vec, dtype=np.float64)
+
+    def Barrier(self):
+        pass
+
+    def gather_objects(self, obj):
+        return [obj]
+
+
+class TorchComm(object):
+    """
+    torch.distributed process group as a communicator: backend "nccl" is RCCL on ROCm (one process per
+    GPU, small float64 tensors on the device), "gloo" runs the same code path on CPU for tests.
+    Exposes the mpi4py-style surface the reference uses (.size .rank .send .recv .Barrier) plus
+    allreduce_sum / gather_objects.
+    """
+
+    def __init__(self, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+        if device is None:
+            device = 'cuda:{0}'.format(int(os.environ.get('LOCAL_RANK', 0))) if self.backend == 'nccl' else 'cpu'
+        self.device = torch.device(device)
+
+    def allreduce_sum(self, vec):
+        t = self.torch.as_tensor(np.ascontiguousarray(vec, dtype=np.float64)).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def Barrier(self):
+        if self.backend == 'nccl':
+            self.dist.barrier(group=self.group, device_ids=[self.device.index or 0])
+        else:
+            self.dist.barrier(group=self.group)
+
+    def gather_objects(self, obj):
+        out = [None] * self.size
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    # point-to-point object passing, for callers that drive this like an mpi4py communicator
+    def send(self, obj, dest, tag=0):
+        self.dist.send_object_list([obj], dst=dest, group=self.group)
+
+    def recv(self, source, tag=0):
+        box = [None]
+        self.dist.recv_object_list(box, src=source, group=self.group)
+        return box[0]
+
+
+def _allreduce(comm, vec):
+    """Sum a small float64 vector over all ranks of `comm` (native collective when it has one)."""
+    if hasattr(comm, 'allreduce_sum'):
+        return comm.allreduce_sum(vec)
+    vec = np.ascontiguousarray(vec, dtype=np.float64)
+    if comm.size == 1:
+        return vec
+    if hasattr(comm, 'allreduce'):            # mpi4py
+        return np.asarray(comm.allreduce(vec))
+    # bare send/recv communicator (the reference's duck type): fold through rank 0
+    if comm.rank == 0:
+        total = vec.copy()
+        for r in range(1, comm.size):
+            total += comm.recv(source=r, tag=777 + r)
+        for r in range(1, comm.size):
+            comm.send(total, dest=r, tag=888 + r)
+        return total
+    comm.send(vec, dest=0, tag=777 + comm.rank)
+    return comm.recv(source=0, tag=888 + comm.rank)
+
+
+def _gather(comm, obj):
+    if hasattr(comm, 'gather_objects'):
+        return comm.gather_objects(obj)
+    if comm.size == 1:
+        return [obj]
+    if comm.rank == 0:
+        return [obj] + [comm.recv(source=r, tag=999 + r) for r in range(1, comm.size)]
+    comm.send(obj, dest=0, tag=999 + comm.rank)
+    return None
+
+
+# ----------------------------------------------------------------------------------------------- #
+class ShardedNMFOA(object):
+    """
+    One rank's share of a DegNorm run: a resident gene shard on one GPU plus the replicated per-sample state.
+    """
+
+    def __init__(self, comm=None, device=None, degnorm_iter=5, downsample_rate=1, min_high_coverage=50,
+                 nmf_iter=100, bins=20, skip_baseline_selection=False, random_state=123, dev=None):
+        self.comm = comm if comm is not None else LocalComm()
+        self.degnorm_iter = abs(int(degnorm_iter))
+        self.nmf_iter = abs(int(nmf_iter))
+        self.bins = abs(int(bins))
+        self.min_high_coverage = max(2, abs(int(min_high_coverage)))
+        self.downsample_rate = abs(int(downsample_rate))
+        if self.downsample_rate > 1:
+            self.min_high_coverage = 2                    # nmf_mpi.py:594-596
+        self.skip_baseline_selection = skip_baseline_selection
+        self.random_state = random_state
+        dev_id = int(os.environ.get('LOCAL_RANK', 0)) if device is None else int(device)
+        # `dev` lets a caller supply an already-open Device (or, in the CPU test-suite, a stand-in with the
+        # same interface); the product path always opens the HIP device and raises if there is none.
+        self.dev = dev if dev is not None else _lib.Device(dev_id)
+        self.kernel_ms = []
+        self.traces = []
+        self.downsample_offsets = None                    # optional (degnorm_iter x n_local) explicit starts
+        self.n_local = 0
+
+    # -- data -------------------------------------------------------------------------------------
+    def load(self, cov_mats, reads):
+        self.dev.upload(cov_mats)
+        self._set_reads(reads)
+
+    def load_packed(self, packed, lengths, p, reads):
+        self.dev.upload_packed(packed, lengths, p)
+        self._set_reads(reads)
+
+    def _set_reads(self, reads):
+        self.x = np.array(reads, dtype=np.float64).reshape(self.dev.n, self.dev.p)
+        self.n_local, self.p = self.dev.n, self.dev.p
+
+    # -- algorithm --------------------------------------------------------------------------------
+    def initialize(self):
+        """ratio-SVD DI scores and the initial normalisation factors (nmf.py:521-535, nmf_mpi.py:681-718)."""
+        est_sums, cov_sums, status = self.dev.ratio_svd_sums()
+        n_bad = _allreduce(self.comm, [float(np.sum(status != 0))])[0]
+        if n_bad > 0:
+            raise ValueError('rank-1 SVD failed on {0} gene(s) during initialisation (all-zero coverage?)'.format(int(n_bad)))
+        self.rho = 1 - (cov_sums / (est_sums + 1))
+        low = self.rho.max(axis=1) < 0.1
+        p = self.p
+        part = np.concatenate([self.x[low].sum(axis=0), self.x.sum(axis=0), [float(low.sum())]])
+        tot = _allreduce(self.comm, part)
+        count_sums = tot[:p] if tot[2 * p] > 0 else tot[p:2 * p]
+        self.norm_factors = count_sums / np.median(count_sums)
+        self.x_weighted = self.x / self.norm_factors
+        self.scale_factors = np.copy(self.norm_factors)
+        self.ran_baseline_selection = np.zeros((self.n_local, self.degnorm_iter), dtype=bool)
+        self._rng = np.random.RandomState(self.random_state)
+        self.x_adj = None
+        self.kernel_ms, self.traces = [], []
+        return self.scale_factors
+
+    def iterate(self, i, want_estimates=False):
+        """One outer DegNorm iteration on this rank's genes + the per-sample all-reduce."""
+        ds = None
+        if self.downsample_rate > 1:
+            ds = (np.asarray(self.downsample_offsets[i], dtype=np.int64) if self.downsample_offsets is not None
+                  else self._rng.randint(0, self.downsample_rate, size=self.n_local).astype(np.int64))
+        rho, flags, trace = self.dev.baseline_iteration(
+            self.scale_factors, nmf_iter=self.nmf_iter, bins=self.bins, min_high_coverage=self.min_high_coverage,
+            downsample_rate=self.downsample_rate, skip_baseline_selection=self.skip_baseline_selection,
+            want_estimates=want_estimates, ds_start=ds)
+        self.kernel_ms.append(self.dev.last_kernel_ms())
+        self.traces.append(trace)
+        rho[rho > 0.9] = 0.9                                          # nmf.py:398-399
+        rho[rho < 0.] = 0.
+        self.ran_baseline_selection[:, i] = flags
+
+        p = self.p
+        xw = self.x_weighted
+        untouched = rho.max(axis=1) == 0                              # nmf.py:155
+        touched = ~untouched
+        A = (xw[touched] / (1 - rho[touched])).sum(axis=0)
+        B = xw[untouched].sum(axis=0)
+        Wl = xw.sum(axis=0)
+        tot = _allreduce(self.comm, np.concatenate([A, B, Wl, [float(untouched.sum())]]))
+        A, B, Wt, n_untouched = tot[:p], tot[p:2 * p], tot[2 * p:3 * p], tot[3 * p]
+        S_pre = A + B                                                 # colsum of the first x_adj  (nmf.py:575)
+        if n_untouched > 0:
+            avg_di = 1 - (Wt / S_pre)                                 # nmf.py:157
+            rho[untouched, :] = avg_di
+            S_post = A + B / (1 - avg_di)                             # colsum of the second x_adj (nmf.py:581)
+        else:
+            S_post = S_pre
+        self.rho = rho
+        self.x_adj = xw / (1 - rho)                                   # nmf.py:581
+        self.norm_factors = S_post / np.median(S_post)                # nmf.py:584
+        self.x_weighted = xw / self.norm_factors                      # nmf.py:587
+        self.scale_factors = self.scale_factors * self.norm_factors   # nmf.py:590
+        return self.scale_factors
+
+    def run(self, want_estimates=True):
+        self.initialize()
+        est = None
+        for i in range(self.degnorm_iter):
+            last = i == self.degnorm_iter - 1
+            self.iterate(i, want_estimates=want_estimates and last)
+            if want_estimates and last:
+                est = self.dev.fetch_estimates()
+        return est
+
+
+# ----------------------------------------------------------------------------------------------- #
+def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate=1, min_high_coverage=50,
+                       nmf_iter=100, bins=20, n_jobs=1, skip_baseline_selection=False, random_state=123,
+                       device=None, dev=None):
+    """
+    Gene-sharded DegNorm run with the reference's signature (nmf_mpi.py:555-580).  Rank 0 holds
+    ``cov_dat`` (OrderedDict gene -> p x L) and ``reads_dat`` (n x p) and ships each worker its contiguous
+    chunk once (nmf_mpi.py:603-629); every rank then keeps its genes on its own GPU.
+    Returns, on rank 0, {'estimates': {gene: p x L}, 'rho', 'x_adj', 'ran_baseline_selection'} in the
+    original gene order (nmf_mpi.py:852-860), None elsewhere.
+    """
+    size, rank = comm.size, comm.rank
+    if rank == 0:
+        all_genes = list(cov_dat.keys())
+        n_genes = len(all_genes)
+        x = np.array(reads_dat, dtype=np.float64)
+        if x.shape[0] != n_genes:
+            raise ValueError('Number of genes in read count matrix not equal to number of coverage matrices!')
+        if not all(z.ndim == 2 for z in cov_dat.values()):
+            raise ValueError('Not all coverage matrices are 2-d arrays!')
+        li_vec = np.array([z.shape[1] for z in cov_dat.values()])
+        if abs(int(downsample_rate)) > 1 and not np.min(li_vec) >= abs(int(downsample_rate)):
+            raise ValueError('downsample_rate is too large; take-every size > at least one gene.')
+        parts = split_into_chunks(list(range(n_genes)), size)        # nmf_mpi.py:605
+        while len(parts) < size:                                      # fewer chunks than ranks: idle ranks get nothing
+            parts.append([])
+        for r in range(1, size):
+            idx = parts[r]
+            comm.send((OrderedDict((all_genes[k], cov_dat[all_genes[k]]) for k in idx), x[idx]), dest=r, tag=333 + r)
+        my_cov = OrderedDict((all_genes[k], cov_dat[all_genes[k]]) for k in parts[0])
+        my_x = x[parts[0]]
+    else:
+        my_cov, my_x = comm.recv(source=0, tag=333 + rank)
+
+    eng = ShardedNMFOA(comm=comm, device=device, degnorm_iter=degnorm_iter, downsample_rate=downsample_rate,
+                       min_high_coverage=min_high_coverage, nmf_iter=nmf_iter, bins=bins,
+                       skip_baseline_selection=skip_baseline_selection, random_state=random_state, dev=dev)
+    if len(my_cov) == 0:
+        raise ValueError('rank {0} received no genes: more ranks than gene chunks (nmf_mpi.py:613)'.format(rank))
+    eng.load(list(my_cov.values()), my_x)
+    est = eng.run(want_estimates=True)
+    logging.info('({0}/{1}) -- finished {2} genes'.format(rank + 1, size, eng.n_local))
+
+    pieces = _gather(comm, (list(my_cov.keys()), est, eng.rho, eng.x_adj, eng.ran_baseline_selection))
+    comm.Barrier()
+    if rank != 0:
+        return None
+    estimates = OrderedDict()
+    for genes_r, est_r, _, _, _ in pieces:
+        for gname, e in zip(genes_r, est_r):
+            estimates[gname] = e
+    return {'estimates': estimates,
+            'rho': np.vstack([pc[2] for pc in pieces]),
+            'x_adj': np.vstack([pc[3] for pc in pieces]),
+            'ran_baseline_selection': np.vstack([pc[4] for pc in pieces])}
+
+
+def save_results(genes_df, estimates, rho, x_adj, ran_baseline_selection, sample_ids=None, output_dir='.'):
+    """Module-level writer with the reference's signature (nmf_mpi.py:448-552; called at __main_mpi__.py:450-456)."""
+    genes = list(estimates.keys())
+    write_results(genes=genes, estimates=estimates, rho=rho, x_adj=x_adj,
+                  ran_baseline_selection=ran_baseline_selection, gene_manifest_df=genes_df,
+                  output_dir=output_dir, sample_ids=sample_ids)

@@ -62,3 +62,80 @@ def test_ratio_svd_sums_vs_oracle(device, oracle):
     assert not status.any() and not status_o.any()
     np.testing.assert_allclose(cov, cov_o, rtol=1e-14)
     np.testing.assert_allclose(est, est_o, rtol=1e-11)
+
+
+def _run_fixture(name, **kw):
+    from collections import OrderedDict
+    from degnorm_amd.nmf import GeneNMFOA
+    G = golden(name)
+    p = int(G['p'])
+    covs = _genes(int(G['seed']), G['gene_ids'], p, int(G['l_min']), int(G['l_max']))
+    np.testing.assert_array_equal([input_checksum(c) for c in covs], G['checksum'])
+    cov_dat = OrderedDict(('gene_%06d' % g, c) for g, c in zip(G['gene_ids'], covs))
+    m = GeneNMFOA(degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']),
+                  downsample_rate=int(G['downsample_rate']), **kw)
+    if 'offsets' in G.files:
+        m.downsample_offsets = G['offsets']
+    est = m.fit(cov_dat, G['reads'])
+    return G, m, est
+
+
+def _check_run(G, m, est, rtol=RTOL):
+    for i in range(int(G['degnorm_iter'])):
+        np.testing.assert_array_equal(m.traces[i][:, 1], G['n_calls'][i])
+        np.testing.assert_array_equal(m.traces[i][:, 2], G['sum_cols'][i])
+    np.testing.assert_array_equal(m.ran_baseline_selection, G['ran_baseline_selection'])
+    np.testing.assert_allclose(m.rho, G['rho'], rtol=rtol, atol=ATOL)
+    np.testing.assert_allclose(m.x_adj, G['x_adj'], rtol=rtol)
+    np.testing.assert_allclose(m.scale_factors, G['scale_factors'], rtol=rtol)
+    np.testing.assert_allclose(m.x_weighted, G['x_weighted'], rtol=rtol)
+    np.testing.assert_allclose(np.vstack([e.sum(axis=1) for e in est]), G['est_rowsum'], rtol=rtol)
+    k = 0
+    while 'est_%d' % k in G.files:
+        np.testing.assert_allclose(est[k], G['est_%d' % k], rtol=rtol, atol=1e-9)
+        k += 1
+    assert m.fitted and len(est) == len(G['gene_ids'])
+
+
+def test_run_config1_vs_reference_golden():
+    """BASELINE.json configs[0]: 100 genes x 4 samples x L=1000, 1 DegNorm iteration, through GeneNMFOA.fit()."""
+    _check_run(*_run_fixture('run_c1'))
+
+
+def test_run_config2_subset_vs_reference_golden():
+    """64-gene draw of configs[1] (p=10, L~U[200,5000]), 3 outer iterations: DI, adjusted counts, scale factors."""
+    G, m, est = _run_fixture('run_c2')
+    _check_run(G, m, est)
+    # the headline tolerance of BASELINE.json, stated: DI within 1e-5 relative of the reference
+    rel = np.abs(m.rho - G['rho']) / np.maximum(np.abs(G['rho']), 1e-300)
+    assert rel.max() < 1e-5
+
+
+def test_run_downsampled_vs_reference_golden():
+    """take-every 50 with the reference's captured systematic-sample offsets (nmf.py:408-453)."""
+    _check_run(*_run_fixture('run_dsamp50'))
+
+
+def test_input_validation_matches_reference_errors(device):
+    from collections import OrderedDict
+    from degnorm_amd.nmf import GeneNMFOA
+    cov = OrderedDict(a=np.ones((3, 300)), b=np.ones((3, 260)))
+    with pytest.raises(ValueError, match='Number of genes in read count matrix'):
+        GeneNMFOA().run(cov, np.ones((3, 3)))
+    with pytest.raises(ValueError, match='downsample_rate is too large'):
+        GeneNMFOA(downsample_rate=280).run(cov, np.ones((2, 3)))
+    with pytest.raises(ValueError, match='Not all coverage matrices are 2-d'):
+        GeneNMFOA().run(OrderedDict(a=np.ones((3, 300)), b=np.ones(300)), np.ones((2, 3)))
+    with pytest.raises(ValueError, match='Model not yet fit'):
+        GeneNMFOA().save_results([], None)
+
+
+def test_degenerate_genes_report_status_not_crash(device):
+    """All-zero gene: the reference raises ArpackError; the device reports per-gene status."""
+    covs = [np.zeros((4, 300)), synth.synth_gene(1, 0, 4, 1000, 1000)[0]]
+    device.upload(covs)
+    est, cov, status = device.ratio_svd_sums()
+    assert status[0] == -1 and status[1] == 0
+    rho, flags, trace = device.baseline_iteration(np.ones(4), nmf_iter=20)
+    assert trace[0, 3] == 0 and not flags[0] and np.all(rho[0] == 0)     # no high coverage at all -> defaults
+    assert trace[1, 6] == 0
