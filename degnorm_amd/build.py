@@ -17,7 +17,8 @@ OBJ = os.path.join(CSRC, 'obj')
 LIB = os.path.join(HERE, 'libdegnorm_amd.so')
 P_LIST = list(range(2, 13))          # keep in sync with DN_FOR_EACH_P in csrc/dn_api.hip
 ARCH = 'gfx950'
-NT = int(os.environ.get('DN_NT', '64'))
+NT = int(os.environ.get('DN_NT', '256'))
+EXTRA = ['-D' + d for d in os.environ.get('DN_DEFINES', '').split() if d]   # e.g. DN_DEFINES='DN_CR=2'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on',
          '-Wall', '-Wno-unused-function']
 
@@ -56,7 +57,7 @@ def build_library(force=False, verbose=False):
         o = os.path.join(OBJ, 'dn_inst_p{0}_nt{1}.o'.format(p, NT))
         objs.append(o)
         if force or _newer(o, [inst] + hdr):
-            jobs.append([hipcc] + FLAGS + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(NT), '-c', inst, '-o', o])
+            jobs.append([hipcc] + FLAGS + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(NT), '-c', inst, '-o', o])
     api = os.path.join(CSRC, 'dn_api.hip')
     o_api = os.path.join(OBJ, 'dn_api.o')
     objs.append(o_api)

@@ -64,7 +64,7 @@ struct dn_handle_s {
     int32_t *d_order = nullptr;
     int32_t *d_counter = nullptr;
     int64_t *d_ds = nullptr;
-    double  *d_ws = nullptr;
+    char    *d_ws = nullptr;
     double  *d_rho = nullptr;
     int32_t *d_flags = nullptr;
     int32_t *d_trace = nullptr;
@@ -80,7 +80,9 @@ struct dn_handle_s {
 
     int slots = 0;
     int32_t S = 0;
-    int64_t slot_stride = 0;
+    int64_t slot_bytes = 0;
+    int32_t lds_cols = 0;
+    size_t dyn_lds = 0;
     double last_scale[dn::P_MAX] = {0};
     bool have_estimate_state = false;
     float last_ms = 0.f;
@@ -198,8 +200,19 @@ static int finish_upload(dn_handle h, const float *host_packed)
     if (per_cu < 1) per_cu = 1;
     h->slots = (int) std::min<int64_t>(n, (int64_t) per_cu * h->n_cus);
     h->S = (h->lmax + 63) & ~63;
-    h->slot_stride = (int64_t) h->ks->slot_doubles_per_col * h->S;
-    HIP_TRY(hipMalloc(&h->d_ws, sizeof(double) * (size_t) h->slot_stride * (size_t) std::max(h->slots, 1)));
+    // slot: Fs, Fb (fp32 [p][S]) + x + lambda spill (fp64 [p][S]) + s_start, residual profile (fp64 [S])
+    h->slot_bytes = (int64_t) h->S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 2 * sizeof(double));
+    HIP_TRY(hipMalloc(&h->d_ws, (size_t) h->slot_bytes * (size_t) std::max(h->slots, 1)));
+    // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
+    {
+        const int64_t lds_per_block = (160 * 1024) / per_cu - (int64_t) h->ks->static_lds_bytes - 256;
+        const int64_t ps = p + (p & 1);                        // LDS column stride in doubles (16-B aligned)
+        int64_t cols = lds_per_block > 0 ? lds_per_block / (8 * ps) : 0;
+        const int64_t want = std::max<int64_t>(0, (int64_t) h->S - (int64_t) h->ks->cr * h->ks->nt);
+        cols = std::min(cols, want) & ~(int64_t) 1;
+        h->lds_cols = (int32_t) cols;
+        h->dyn_lds = (size_t) cols * 8 * (size_t) ps;
+    }
     return DN_OK;
 }
 
@@ -324,11 +337,12 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.order = h->d_order; a.counter = h->d_counter;
     a.ds_start = nullptr;
     a.ws = h->d_ws; a.rho = h->d_rho; a.flags = h->d_flags; a.trace = h->d_trace; a.kfin = h->d_kfin; a.emode = h->d_emode;
-    a.svec = h->d_svec; a.svoff = h->d_svoff; a.slot_stride = h->slot_stride; a.n_genes = (int32_t) h->n; a.S = h->S;
+    a.svec = h->d_svec; a.svoff = h->d_svoff; a.slot_bytes = h->slot_bytes; a.n_genes = (int32_t) h->n; a.S = h->S;
+    a.lds_cols = h->lds_cols;
     a.T = prm->nmf_iter; a.bins = prm->bins; a.min_hc = prm->min_high_coverage; a.rate = prm->downsample_rate;
     a.skip = prm->skip_baseline_selection ? 1 : 0; a.want_est = prm->want_estimates ? 1 : 0;
-    for (int i = 0; i < h->p; i++) { a.scale[i] = scale[i]; h->last_scale[i] = scale[i]; }
-    for (int i = h->p; i < dn::P_MAX; i++) a.scale[i] = 1.0;
+    for (int i = 0; i < h->p; i++) { a.scale[i] = scale[i]; a.inv_scale[i] = 1.0 / scale[i]; h->last_scale[i] = scale[i]; }
+    for (int i = h->p; i < dn::P_MAX; i++) { a.scale[i] = 1.0; a.inv_scale[i] = 1.0; }
     if (prm->downsample_rate > 1) {
         HIP_TRY(hipMemcpyAsync(h->d_ds, ds_start, sizeof(int64_t) * (size_t) h->n, hipMemcpyHostToDevice, h->stream));
         a.ds_start = h->d_ds;
@@ -336,8 +350,10 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * 4, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_trace, 0, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, h->stream));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    h->ks->baseline(a, h->slots, h->stream);
-    HIP_TRY(hipGetLastError());
+    {
+        const int lrc = h->ks->baseline(a, h->slots, h->dyn_lds, h->stream);
+        if (lrc != 0) return fail(DN_E_HIP, std::string("k_baseline launch: ") + hipGetErrorString((hipError_t) lrc));
+    }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));

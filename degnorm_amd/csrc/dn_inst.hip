@@ -14,11 +14,24 @@
 #define DN_STR_(a) #a
 #define DN_STR(a) DN_STR_(a)
 
+#ifndef DN_CR
+#define DN_CR_RAW (40 / DN_P)
+#define DN_CR (DN_CR_RAW < 1 ? 1 : (DN_CR_RAW > 12 ? 12 : DN_CR_RAW))
+#endif
+
 namespace dn {
 
-static void launch_baseline(const IterArgs &a, int grid, hipStream_t s)
+static int launch_baseline(const IterArgs &a, int grid, size_t dyn_lds, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_baseline<DN_P, DN_NT>), dim3(grid), dim3(DN_NT), 0, s, a);
+    static size_t configured = 0;
+    if (dyn_lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_baseline<DN_P, DN_NT, DN_CR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn_lds);
+        if (e != hipSuccess) return (int) e;
+        configured = dyn_lds;
+    }
+    hipLaunchKernelGGL((k_baseline<DN_P, DN_NT, DN_CR>), dim3(grid), dim3(DN_NT), dyn_lds, s, a);
+    return (int) hipGetLastError();
 }
 
 static void launch_init(const InitArgs &a, int grid, hipStream_t s)
@@ -35,7 +48,7 @@ static int blocks_per_cu(int which)
 {
     int nb = 0;
     hipError_t e;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline<DN_P, DN_NT>, DN_NT, 0);
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline<DN_P, DN_NT, DN_CR>, DN_NT, 0);
     else            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd<DN_P, DN_NT>, DN_NT, 0);
     return e == hipSuccess ? nb : 0;
 }
@@ -44,8 +57,8 @@ const KernelSet *DN_CAT(kernel_set_p, DN_P)()
 {
     static const KernelSet ks = {
         DN_P, DN_NT, launch_baseline, launch_init, launch_est, blocks_per_cu,
-        (size_t) (3 * DN_P + 2),
-        "k_baseline<" DN_STR(DN_P) "," DN_STR(DN_NT) ">",
+        DN_CR, sizeof(Smem<DN_P, DN_NT>) + sizeof(GeneState<DN_P>),
+        "k_baseline<" DN_STR(DN_P) "," DN_STR(DN_NT) "," DN_STR(DN_CR) ">",
     };
     return &ks;
 }

@@ -21,6 +21,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef DN_GRAM_T
+#define DN_GRAM_T double
+#endif
+#ifndef DN_MIN_WAVES
+#define DN_MIN_WAVES 1
+#endif
+
 namespace dn {
 
 constexpr int TRACE_LEN = 48;
@@ -46,7 +53,7 @@ struct IterArgs {
     const int32_t *order;      // work queue: gene ids, longest first
     int32_t       *counter;    // queue head
     const int64_t *ds_start;   // per gene, or nullptr
-    double        *ws;         // scratch: slots x slot_stride doubles
+    char          *ws;         // scratch: slots x slot_bytes
     double        *rho;        // n x p
     int32_t       *flags;      // n
     int32_t       *trace;      // n x TRACE_LEN
@@ -54,11 +61,13 @@ struct IterArgs {
     int32_t       *emode;      // n
     double        *svec;       // per gene s_start vectors (only when want_est), at svoff[g]
     const int64_t *svoff;
-    int64_t        slot_stride;
+    int64_t        slot_bytes;
     int32_t        n_genes;
     int32_t        S;          // column stride of the scratch arrays (>= longest gene, multiple of 64)
+    int32_t        lds_cols;   // lambda columns held in LDS (dynamic shared memory = 8 * p * lds_cols bytes)
     int32_t        T, bins, min_hc, rate, skip, want_est;
     double         scale[P_MAX];
+    double         inv_scale[P_MAX];
 };
 
 struct InitArgs {
@@ -87,9 +96,9 @@ struct EstArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// LDS layout of one workgroup.
+// LDS layout of one workgroup (static part; the lambda tile is dynamic shared memory behind it).
 // ---------------------------------------------------------------------------------------------------
-constexpr int RED_ROWS = 32;                 // entries reduced per round
+constexpr int RED_ROWS = 8;                  // entries reduced per round
 constexpr int RED_LD = 66;                   // row stride in doubles: 528 B, 16-B aligned, bank-skewed by 4 dwords
 constexpr int WAVE_RED_DOUBLES = RED_ROWS * RED_LD;
 
@@ -97,8 +106,10 @@ template <int P, int NT>
 struct Smem {
     static constexpr int W = NT / 64;
     static constexpr int NG = P * (P + 1) / 2;
-    double red[W][WAVE_RED_DOUBLES];         // per-wave transposed-reduce tile
-    double xw[W][NG > 64 ? NG : 64];         // per-wave totals (cross-wave combine / broadcast)
+    static constexpr int NX = NG > 64 ? NG : 64;
+    double red[W][WAVE_RED_DOUBLES];         // per-wave transposed-reduce tile (wave-private)
+    double xw[W][NX];                        // per-wave totals (cross-wave combine)
+    double tot[NX];                          // block totals (broadcast)
     double ss[MAX_BINS];                     // per-bin mean squared residual
     int32_t alive[MAX_BINS];                 // original ids of the surviving bins, in order
     int32_t cnt[W];                          // per-wave hi-coverage counts
@@ -108,65 +119,100 @@ struct Smem {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-template <int NT>
-__device__ __forceinline__ void block_sync() { __syncthreads(); }
-
-// Sum each of the N register values over the 64 lanes of a wave and leave the totals in every lane.
-// Transposed tree through LDS: lane l writes its N partials as column l of an [entry][lane] tile; lane t
-// then adds 32 lanes of entry (t & 31) in a fixed order, the two halves meet with one shuffle, totals go
-// back through LDS as broadcast reads.  ~3 LDS ops per value instead of 12 ds_bpermute for a butterfly.
-template <int N>
-__device__ __forceinline__ void wave_sum_bcast(double (&g)[N], double *tile, double *tot)
+// LDS traffic inside one wave needs no s_barrier: a wave's DS instructions execute in order.  This only stops
+// the compiler from moving LDS accesses across the point.
+__device__ __forceinline__ void wave_fence()
 {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *q)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) a), hi = __builtin_amdgcn_readfirstlane((unsigned) (a >> 32));
+    return reinterpret_cast<T *>(((unsigned long long) hi << 32) | lo);
+}
+
+__device__ __forceinline__ double uniform(double v)
+{
+    // value is identical in every lane: move it to scalar registers so it costs no VGPRs
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Cross-lane moves inside a row of 16 lanes without touching LDS (DPP): quad_perm [1,0,3,2], [2,3,0,1] and
+// row_half_mirror give an all-reduce over each group of 8 lanes in three steps.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sum8(double s)
+{
+    s += dpp_mov<0xB1>(s);      // quad_perm [1,0,3,2]
+    s += dpp_mov<0x4E>(s);      // quad_perm [2,3,0,1]
+    s += dpp_mov<0x141>(s);     // row_half_mirror: lane i <-> 7 - i of each 8
+    return s;
+}
+
+// Block-wide sum of N register values; the totals are left in sm.tot[0..N), bit-identical for every reader
+// (the wave-uniform branches of the state machine rely on that).
+// Per wave: transposed tree through a private LDS tile -- lane l writes 8 of its partials as column l of an
+// [entry][lane] tile, lane (e, seg) adds 8 lanes of entry e in a fixed order, three DPP steps finish the 64
+// lanes: ~4 LDS/ALU ops per value where a butterfly needs 18.  Then one cross-wave add through LDS.
+template <int N, int P, int NT, typename VT>
+__device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm)
+{
+    static_assert(N <= Smem<P, NT>::NX, "xw too small");
+    constexpr int W = NT / 64;
     constexpr int ROUNDS = (N + RED_ROWS - 1) / RED_ROWS;
-    const int lane = lane_id();
-    const int e = lane & 31, h = lane >> 5;
-    double t[ROUNDS];
+    const int lane = lane_id(), w = wave_id();
+    const int e = lane >> 3, seg = lane & 7;
+    double *dst = (W > 1) ? sm.xw[w] : sm.tot;
+    double *tile = sm.red[w];
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
 #pragma unroll
         for (int q = 0; q < RED_ROWS; q++) {
-            if (r * RED_ROWS + q < N) tile[q * RED_LD + lane] = g[r * RED_ROWS + q];
+            if (r * RED_ROWS + q < N) tile[q * RED_LD + lane] = (double) g[r * RED_ROWS + q];
         }
-        __syncthreads();
+        wave_fence();
         double s = 0.0;
-        if (r * RED_ROWS + e < N) {
-            const double2 *row = reinterpret_cast<const double2 *>(tile + e * RED_LD + h * 32);
+        {
+            const double2 *row = reinterpret_cast<const double2 *>(tile + e * RED_LD + seg * 8);
 #pragma unroll
-            for (int c = 0; c < 16; c++) { double2 v = row[c]; s += v.x; s += v.y; }
+            for (int c = 0; c < 4; c++) { const double2 v = row[c]; s += v.x; s += v.y; }
         }
-        s += __shfl_xor(s, 32);
-        t[r] = s;
-        __syncthreads();
+        s = sum8(s);
+        if (seg == 0 && r * RED_ROWS + e < N) dst[r * RED_ROWS + e] = s;
+        wave_fence();
     }
+    if constexpr (W > 1) {
+        __syncthreads();
+        if (threadIdx.x < N) {
+            double s = sm.xw[0][threadIdx.x];
 #pragma unroll
-    for (int r = 0; r < ROUNDS; r++)
-        if (lane < 32 && r * RED_ROWS + lane < N) tot[r * RED_ROWS + lane] = t[r];
+            for (int ww = 1; ww < W; ww++) s += sm.xw[ww][threadIdx.x];
+            sm.tot[threadIdx.x] = s;
+        }
+    }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < N; i++) g[i] = tot[i];
+    // totals are in sm.tot[0..N); no trailing barrier: the next writer of tot / xw sits behind the next
+    // call's first barrier
 }
 
-// Block-wide sum of N values, result in every thread.  All waves add the per-wave totals in the same order,
-// so every thread holds bit-identical results (the uniform branches below rely on that).
 template <int N, int P, int NT>
 __device__ __forceinline__ void block_sum(double (&g)[N], Smem<P, NT> &sm)
 {
-    static_assert(N <= (Smem<P, NT>::NG > 64 ? Smem<P, NT>::NG : 64), "xw too small");
-    constexpr int W = NT / 64;
-    const int w = wave_id();
-    wave_sum_bcast<N>(g, sm.red[w], sm.xw[w]);
-    if constexpr (W > 1) {
-        __syncthreads();
+    block_sum_lds<N, P, NT, double>(g, sm);
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            double s = sm.xw[0][i];
-#pragma unroll
-            for (int ww = 1; ww < W; ww++) s += sm.xw[ww][i];
-            g[i] = s;
-        }
-    }
-    __syncthreads();
+    for (int i = 0; i < N; i++) g[i] = sm.tot[i];
 }
 
 template <int N, int P, int NT>
@@ -205,33 +251,47 @@ __device__ __forceinline__ double wave_sum1(double v)
 
 // ---------------------------------------------------------------------------------------------------
 // Top eigenpair of the symmetric PSD p x p matrix G (packed lower triangle, idx(i,j) = i(i+1)/2 + j).
-// Power iteration, warm-started from u, run by every lane on identical data until ||u_new - u||^2 is at
-// the fp64 rounding floor; the reference's ARPACK call (tol = 0) converges to machine precision too.
-// Entries of x + lambda are non-negative, so the Perron vector is non-negative and a positive start is
-// never orthogonal to it.  Returns the number of steps; theta = u^T G u (= sigma^2).
+// Shifted power iteration, warm-started from u, run by every lane on identical data until
+// ||u_new - u||^2 <= 1e-24 (the step after that shrinks the error by the convergence ratio again, so u is at
+// fp64 round-off like the reference's ARPACK call with tol = 0).  The shift mu = mean of the non-dominant
+// eigenvalues ~ (trace - theta) / (p - 1) moves the noise cluster to ~0 and never slows convergence while
+// mu <= lambda_2.  Entries of x + lambda are non-negative, so the Perron vector is non-negative and a
+// positive start is never orthogonal to it.  Returns the number of steps; theta = u^T G u (= sigma^2).
 // ---------------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void sym_matvec(const double (&G)[P * (P + 1) / 2], const double (&u)[P], double (&y)[P])
+{
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const int a = i > j ? i : j, b = i > j ? j : i;
+            acc = fma(G[a * (a + 1) / 2 + b], u[j], acc);
+        }
+        y[i] = acc;
+    }
+}
+
 template <int P>
 __device__ __forceinline__ int top_eig(const double (&G)[P * (P + 1) / 2], double (&u)[P], double &theta)
 {
-    int steps = 0;
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) tr += G[i * (i + 1) / 2 + i];
+    double y[P];
+    sym_matvec<P>(G, u, y);
     double th = 0.0;
-    for (; steps < 4000;) {
-        double y[P];
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < P; j++) {
-                const int a = i > j ? i : j, b = i > j ? j : i;
-                acc = fma(G[a * (a + 1) / 2 + b], u[j], acc);
-            }
-            y[i] = acc;
-        }
+    for (int i = 0; i < P; i++) th = fma(u[i], y[i], th);
+    int steps = 1;
+    for (;;) {
+        // y = G u is current; th = u.y
+        double mu = (tr - th) / (double) (P > 1 ? P - 1 : 1);
+        mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
         double n2 = 0.0;
-        th = 0.0;
 #pragma unroll
-        for (int i = 0; i < P; i++) { n2 = fma(y[i], y[i], n2); th = fma(u[i], y[i], th); }
-        steps++;
+        for (int i = 0; i < P; i++) { y[i] = fma(-mu, u[i], y[i]); n2 = fma(y[i], y[i], n2); }
         if (!(n2 > 0.0)) { theta = 0.0; return steps; }
         const double inv = 1.0 / sqrt(n2);
         double d2 = 0.0;
@@ -242,34 +302,120 @@ __device__ __forceinline__ int top_eig(const double (&G)[P * (P + 1) / 2], doubl
             d2 = fma(d, d, d2);
             u[i] = un;
         }
-        if (d2 <= 1e-27) break;
-    }
-    // Rayleigh quotient of the final vector
-    {
-        double t2 = 0.0;
+        sym_matvec<P>(G, u, y);
+        th = 0.0;
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < P; j++) {
-                const int a = i > j ? i : j, b = i > j ? j : i;
-                acc = fma(G[a * (a + 1) / 2 + b], u[j], acc);
-            }
-            t2 = fma(u[i], acc, t2);
-        }
-        th = t2;
+        for (int i = 0; i < P; i++) th = fma(u[i], y[i], th);
+        steps++;
+        if (d2 <= 1e-24 || steps >= 4000) break;
     }
     theta = th;
     return steps;
 }
 
+// Row-distributed form of the same iteration, used by the hot loop.  After block_sum_lds the Gram totals sit in
+// LDS; lane l keeps only row (l & 15) of G, computes one component of G v per step and the p components are
+// broadcast back through v_readlane into scalar registers (v is wave-uniform).  A step is then p FMAs + 2p
+// readlanes instead of p^2 FMAs in every lane.  Two unnormalised steps run between convergence checks
+// (fp64 range absorbs the growth); the check predicts the current error from the contraction seen between
+// consecutive checks and stops at ~1e-13.  All waves run it redundantly on identical data.
 template <int P>
-__device__ __forceinline__ void gram_add(double (&G)[P * (P + 1) / 2], const double (&a)[P])
+__device__ __forceinline__ void bcast_rows(double y, double (&yb)[P])
 {
+    const int lo = __double2loint(y), hi = __double2hiint(y);
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        yb[j] = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+}
+
+template <int P>
+__device__ __forceinline__ double row_dot(const double (&Gr)[P], const double (&v)[P])
+{
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j + 1 < P; j += 2) { a0 = fma(Gr[j], v[j], a0); a1 = fma(Gr[j + 1], v[j + 1], a1); }
+    if (P & 1) a0 = fma(Gr[P - 1], v[P - 1], a0);
+    return a0 + a1;
+}
+
+template <int P>
+__device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], double &theta)
+{
+    static_assert(P <= 16, "row-distributed solver maps rows to the 16 lanes of a DPP row");
+    const int r = (lane_id() & 15) < P ? (lane_id() & 15) : P - 1;
+    double Gr[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const int a = r > j ? r : j, b = r > j ? j : r;
+        Gr[j] = tot[a * (a + 1) / 2 + b];
+    }
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) tr += tot[i * (i + 1) / 2 + i];
+
+    double v[P], w[P];
+    bcast_rows<P>(row_dot<P>(Gr, u), w);                               // w = G u
+    double th = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) th = fma(u[i], w[i], th);
+    if (!(th > 0.0)) { theta = 0.0; return 1; }
+    double mu = (tr - th) * (1.0 / (double) (P > 1 ? P - 1 : 1));
+    mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
+#pragma unroll
+    for (int j = 0; j < P; j++) Gr[j] = (j == r) ? Gr[j] - mu : Gr[j];  // G - mu I
+#pragma unroll
+    for (int i = 0; i < P; i++) v[i] = fma(-mu, u[i], w[i]);             // first shifted step
+    int steps = 1;
+    double d2_prev = -1.0;
+    for (;;) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) n2 = fma(v[i], v[i], n2);
+        if (!(n2 > 0.0)) { theta = 0.0; return steps; }
+        // 1/sqrt(n2): hardware estimate + two Newton steps (only the direction of v matters; u.u = 1 to round-off)
+        double inv = __builtin_amdgcn_rsq(n2);
+        inv = inv * fma(-0.5 * n2 * inv, inv, 1.5);
+        inv = inv * fma(-0.5 * n2 * inv, inv, 1.5);
+        double d2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const double un = v[i] * inv;
+            const double d = un - u[i];
+            d2 = fma(d, d, d2);
+            u[i] = un;
+        }
+        // contraction between checks: d2 / d2_prev ~ rho^(2 * steps between checks); predicted current error^2 ~ d2 * ratio
+        bool done = d2 <= 1e-26;
+        if (d2_prev > 0.0) {
+            const double ratio = d2 / d2_prev;
+            if (ratio < 0.25 && 4.0 * d2 * ratio <= 1e-26) done = true;
+        }
+        if (done || steps >= 4000) break;
+        d2_prev = d2;
+        bcast_rows<P>(row_dot<P>(Gr, u), w);                           // two plain steps, no normalisation in between
+        bcast_rows<P>(row_dot<P>(Gr, w), v);
+        steps += 2;
+    }
+    bcast_rows<P>(row_dot<P>(Gr, u), w);                               // Rayleigh quotient of the unshifted matrix
+    th = mu;
+#pragma unroll
+    for (int i = 0; i < P; i++) th = fma(u[i], w[i], th);
+    theta = th;
+    return steps + 1;
+}
+
+typedef DN_GRAM_T gram_t;      // per-lane Gram accumulators: double (exact mode) or float (mixed mode)
+
+template <int P, typename T>
+__device__ __forceinline__ void gram_add(T (&G)[P * (P + 1) / 2], const double (&a)[P])
+{
+    T b[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) b[i] = (T) a[i];
 #pragma unroll
     for (int i = 0; i < P; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = fma(a[i], a[j], G[i * (i + 1) / 2 + j]);
+        for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = fma(b[i], b[j], G[i * (i + 1) / 2 + j]);
 }
 
 template <int P> __device__ __forceinline__ double vmax(const double (&v)[P])
@@ -310,112 +456,6 @@ template <int P> __device__ __forceinline__ double median_of(const double (&v)[P
     return 0.5 * (lo + hi);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// One nmf() call on the compacted working matrix Fb (p x n, row stride S) -- nmf.py:78-107.
-// On return u, theta describe the last SVD; sums[] = { sum_j s_j, clamped row sums (P), row sums of Fb (P) };
-// rs[k] = squared relative residual of column k (nmf.py:280-282), sv[k] = s_k when store_s.
-// ---------------------------------------------------------------------------------------------------
-template <int P, int NT>
-__device__ __forceinline__ int nmf_call(const double *__restrict__ Fb, double *__restrict__ Lm,
-                                        double *__restrict__ rs, double *__restrict__ sv,
-                                        int n, int S, int T, bool first, Smem<P, NT> &sm,
-                                        double (&u)[P], double &theta, double (&sums)[2 * P + 1], int &steps)
-{
-    constexpr int NG = P * (P + 1) / 2;
-    const int tid = threadIdx.x;
-    double G[NG];
-
-    // cold start: SVD of x itself (nmf.py:88)
-#pragma unroll
-    for (int i = 0; i < NG; i++) G[i] = 0.0;
-    for (int k = tid; k < n; k += NT) {
-        double x[P];
-#pragma unroll
-        for (int i = 0; i < P; i++) x[i] = Fb[(size_t) i * S + k];
-        gram_add<P>(G, x);
-    }
-    block_sum<NG, P, NT>(G, sm);
-    {
-        double tr = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; i++) tr += G[i * (i + 1) / 2 + i];
-        if (!(tr > 0.0)) return ST_ARPACK;
-    }
-    const double u0 = 1.0 / sqrt((double) P);
-#pragma unroll
-    for (int i = 0; i < P; i++) u[i] = u0;
-    steps += top_eig<P>(G, u, theta);
-
-    const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
-    for (int t = 0; t < T; t++) {
-#pragma unroll
-        for (int i = 0; i < NG; i++) G[i] = 0.0;
-        for (int k = tid; k < n; k += NT) {
-            double x[P], l[P], a[P];
-#pragma unroll
-            for (int i = 0; i < P; i++) x[i] = Fb[(size_t) i * S + k];
-            if (t > 0) {
-#pragma unroll
-                for (int i = 0; i < P; i++) l[i] = Lm[(size_t) i * S + k];
-            } else {
-#pragma unroll
-                for (int i = 0; i < P; i++) l[i] = 0.0;                // lmbda = zeros, nmf.py:90
-            }
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < P; i++) s = fma(u[i], x[i] + l[i], s);  // E_j * sigma = u . (x + lambda)_j
-#pragma unroll
-            for (int i = 0; i < P; i++) {
-                const double res = fma(u[i], s, -x[i]);                // est - x          nmf.py:94
-                double ln = fma(-c, res, l[i]);                        // lmbda -= c * res nmf.py:95
-                ln = ln < 0.0 ? 0.0 : ln;                              //                  nmf.py:96
-                Lm[(size_t) i * S + k] = ln;
-                a[i] = x[i] + ln;                                      // x + lmbda        nmf.py:97
-            }
-            gram_add<P>(G, a);
-        }
-        block_sum<NG, P, NT>(G, sm);
-        steps += top_eig<P>(G, u, theta);
-    }
-
-    // final pass: K E of the last SVD, its row sums, the clamped row sums and the residual profile.
-    double acc[2 * P + 1];
-#pragma unroll
-    for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
-    for (int k = tid; k < n; k += NT) {
-        double x[P];
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; i++) {
-            x[i] = Fb[(size_t) i * S + k];
-            s = fma(u[i], x[i] + Lm[(size_t) i * S + k], s);
-        }
-        acc[0] += s;
-        double rmax = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; i++) {
-            const double ke = u[i] * s;
-            acc[1 + i] += ke < x[i] ? x[i] : ke;                       // KE[KE < F] = F     nmf.py:318
-            acc[1 + P + i] += x[i];
-            double d = ke - x[i];
-            if (!first) d = d < 0.0 ? 0.0 : d;                         // residual of the clamped KE on later trips
-            const double r = d / (x[i] + 1.0);                         // (KE - F) / (F + 1) nmf.py:282
-            const double r2 = r * r;
-            rmax = r2 > rmax ? r2 : rmax;
-        }
-        rs[k] = rmax;
-        if (first) sv[k] = s;
-    }
-    block_sum<2 * P + 1, P, NT>(acc, sm);
-#pragma unroll
-    for (int i = 0; i < 2 * P + 1; i++) sums[i] = acc[i];
-    return ST_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_baseline: the per-gene state machine.  Gene-level vectors (rho, K, ...) are wave-uniform and live in
-// LDS (GeneState) so that the registers belong to the Gram accumulators of the inner passes.
-// ---------------------------------------------------------------------------------------------------
 template <int P>
 struct GeneState {
     double sumF[P];      // row sums of F_start                                   nmf.py:241, :337
@@ -424,7 +464,308 @@ struct GeneState {
     double us[P];        // u of the first nmf() call (K_start / sigma)           nmf.py:250
     double rho_fb[P];    // DI of max(K_start E_start, F_start)                   nmf.py:345-346, :352-353
     double sig0;         // sigma of the first call
+    double inv[P];       // 1 / scale factors
+    double u[P];         // outputs of the last nmf() call: top left singular vector,
+    double theta;        //   sigma^2,
+    double sums[2 * P + 1];   // { sum_j s_j, clamped row sums (P), row sums of Fb (P) }
+    int32_t steps;       //   power-iteration steps spent (accumulated over the gene's calls)
+    int32_t status;
+    long long stamp[4];  // diagnostic builds (DN_STAMP): cycles in pass / reduction / eigen-solver
 };
+
+// The workgroup's LDS objects live at namespace scope so that the out-of-line nmf_call() addresses them with
+// ds_* instructions (a reference parameter would decay to a flat pointer).  One translation unit = one (p, NT).
+#ifdef DN_P
+__shared__ Smem<DN_P, DN_NT> g_sm;
+__shared__ GeneState<DN_P> g_gs;
+extern __shared__ __attribute__((aligned(16))) double g_lam[];      // lambda LDS tier: [p][lds_cols]
+typedef const float __attribute__((address_space(1))) *gF_cptr;      // compacted raw counts (fp32, exact)
+typedef double __attribute__((address_space(1))) *gdouble_ptr;
+
+// ---------------------------------------------------------------------------------------------------
+// One nmf() call on the compacted working matrix (p x n) -- nmf.py:78-107.
+//
+// Where the data lives.  Fb: the raw fp32 counts of the n active columns (row stride S) in the workgroup's
+// scratch slot -- read-only inside the call, ~40 B per column per pass, served by the XCD's L2 because the
+// slot is touched by this CU only.  F = x * (1/s_i) is formed in registers.  lambda (fp64, read AND written
+// every pass) never leaves the chip when the gene fits: column k of lane tid = k % NT sits
+//     k <  CR*NT            in this lane's registers (lr[c][i], c = k / NT)                  "register tier"
+//     k <  CR*NT + lds_cols in the dynamic LDS tile lam[i * lds_cols + (k - CR*NT)]           "LDS tier"
+//     else                  in the slot's global spill array Lg[i * S + k]                    "HBM tier"
+// On return u, theta describe the last SVD; sums[] = { sum_j s_j, clamped row sums (P), row sums of Fb (P) };
+// rs[k] = squared relative residual of column k (nmf.py:280-282), sv[k] = s_k when `first`.
+// ---------------------------------------------------------------------------------------------------
+// The on-chip state of a column is a = x + lambda rather than lambda itself:
+//     lambda' = max(lambda - c (K E - x), 0)   (nmf.py:94-96)   <=>   a' = x + lambda' = max(a - c (u s - x), x),
+// with s = u . a (E_j sigma), so a pass costs 3 fp64 ops per element plus the p(p+1)/2 Gram products and
+// x + lambda is never re-formed (nmf.py:97).  lambda is not needed by itself anywhere.
+template <int P>
+__device__ __forceinline__ void col_step(const double (&f)[P], double (&a)[P], const double (&u)[P], double c,
+                                         gram_t (&G)[P * (P + 1) / 2])
+{
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i + 1 < P; i += 2) { s0 = fma(u[i], a[i], s0); s1 = fma(u[i + 1], a[i + 1], s1); }
+    if (P & 1) s0 = fma(u[P - 1], a[P - 1], s0);
+    const double s = s0 + s1;                                          // E_j * sigma = u . (x + lambda)_j
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const double res = fma(u[i], s, -f[i]);                        // est - x                       nmf.py:94
+        a[i] = fmax(fma(-c, res, a[i]), f[i]);                         // x + max(lambda - c res, 0)    nmf.py:95-97
+    }
+    gram_add<P>(G, a);
+}
+
+template <int P>
+__device__ __forceinline__ void col_final(const double (&f)[P], const double (&a)[P], const double (&u)[P], bool first,
+                                          double (&acc)[2 * P + 1], double &s_out, double &r_out)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) s = fma(u[i], a[i], s);
+    acc[0] += s;
+    double rmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const double ke = u[i] * s;
+        acc[1 + i] += ke < f[i] ? f[i] : ke;                           // KE[KE < F] = F     nmf.py:318
+        acc[1 + P + i] += f[i];
+        double d = ke - f[i];
+        if (!first) d = d < 0.0 ? 0.0 : d;                             // residual of the clamped KE on later trips
+        const double r = d / (f[i] + 1.0);                             // (KE - F) / (F + 1) nmf.py:282
+        const double r2 = r * r;
+        rmax = r2 > rmax ? r2 : rmax;
+    }
+    s_out = s; r_out = rmax;
+}
+
+template <int PS>
+__device__ __forceinline__ void lds_col_read(const double *col, double (&a)[PS])
+{
+#pragma unroll
+    for (int i = 0; i < PS; i += 2) { const double2 v = *reinterpret_cast<const double2 *>(col + i); a[i] = v.x; a[i + 1] = v.y; }
+}
+template <int PS>
+__device__ __forceinline__ void lds_col_write(double *col, const double (&a)[PS])
+{
+#pragma unroll
+    for (int i = 0; i < PS; i += 2) *reinterpret_cast<double2 *>(col + i) = make_double2(a[i], a[i + 1]);
+}
+
+template <int P>
+__device__ __forceinline__ void load_x(gF_cptr Fb, int S, int k, float (&x)[P])
+{
+#pragma unroll
+    for (int i = 0; i < P; i++) x[i] = Fb[(size_t) i * S + k];
+}
+
+template <int P>
+__device__ __forceinline__ void load_f(gF_cptr Fb, int S, int k, const double (&inv)[P], double (&f)[P])
+{
+#pragma unroll
+    for (int i = 0; i < P; i++) f[i] = (double) Fb[(size_t) i * S + k] * inv[i];
+}
+
+// Out of line on purpose: the call has its own register allocation (Gram accumulators + one column in
+// flight), independent of what the state machine keeps live, so that two waves fit on a SIMD.
+template <int P, int NT, int CR>
+__device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_, double *rs_, double *sv_,
+                                                   int n, int S, int nL, int T, int first_i)
+{
+    Smem<P, NT> &sm = g_sm;
+    double *lam = g_lam;
+    // every argument is wave-uniform but arrives in vector registers (calling convention): move them to
+    // scalar registers so that all row-base arithmetic below is SALU and costs no VGPRs
+    gF_cptr Fb = (gF_cptr) uniform_ptr(Fb_);
+    gdouble_ptr Lg = (gdouble_ptr) uniform_ptr(Lg_);
+    gdouble_ptr rs = (gdouble_ptr) uniform_ptr(rs_);
+    gdouble_ptr sv = (gdouble_ptr) uniform_ptr(sv_);
+    n = __builtin_amdgcn_readfirstlane(n);
+    S = __builtin_amdgcn_readfirstlane(S);
+    nL = __builtin_amdgcn_readfirstlane(nL);
+    T = __builtin_amdgcn_readfirstlane(T);
+    const bool first = __builtin_amdgcn_readfirstlane(first_i) != 0;
+    double inv[P], u[P], theta = 0.0;
+    int steps = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) inv[i] = uniform(g_gs.inv[i]);
+    long long stamp[4] = {0, 0, 0, 0};
+#ifdef DN_STAMP
+#define DN_T0() const long long t0_ = __builtin_amdgcn_s_memtime()
+#define DN_T1(slot) stamp[slot] += __builtin_amdgcn_s_memtime() - t0_
+#else
+#define DN_T0()
+#define DN_T1(slot) (void) stamp
+#endif
+    constexpr int NG = P * (P + 1) / 2;
+    constexpr int NR = CR * NT;
+    constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
+    const int tid = threadIdx.x;
+    const int nLe = (n < NR + nL) ? n : NR + nL;          // end of the LDS tier
+    gram_t G[NG];
+    double lr[CR > 0 ? CR : 1][P];
+
+    // cold start: SVD of x itself (nmf.py:88)
+#pragma unroll
+    for (int i = 0; i < NG; i++) G[i] = 0.0;
+#pragma clang loop unroll(disable)
+    for (int k = tid; k < n; k += NT) {
+        double f[P];
+        load_f<P>(Fb, S, k, inv, f);
+        gram_add<P>(G, f);
+    }
+    block_sum_lds<NG, P, NT, gram_t>(G, sm);
+    {
+        double tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) tr += sm.tot[i * (i + 1) / 2 + i];
+        if (!(tr > 0.0)) { if (tid == 0) g_gs.status = ST_ARPACK; __syncthreads(); return; }
+    }
+    const double u0 = 1.0 / sqrt((double) P);
+#pragma unroll
+    for (int i = 0; i < P; i++) u[i] = u0;
+    steps += top_eig_rows<P>(sm.tot, u, theta);
+#pragma unroll
+    for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
+
+#pragma unroll
+    for (int cc = 0; cc < CR; cc++) {                                  // lmbda = zeros (nmf.py:90): a = x
+        const int k = cc * NT + tid;
+        if (k < n) load_f<P>(Fb, S, k, inv, lr[cc]);
+    }
+
+    const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < T; t++) {
+#pragma unroll
+        for (int i = 0; i < NG; i++) G[i] = 0.0;
+        { DN_T0();
+        // register tier
+#pragma unroll
+        for (int cc = 0; cc < CR; cc++) {
+            const int k = cc * NT + tid;
+            if (k < n) {
+                double f[P];
+                load_f<P>(Fb, S, k, inv, f);
+                col_step<P>(f, lr[cc], u, c, G);
+            }
+        }
+        // LDS tier.  Column o keeps its p doubles contiguously (stride PS = p rounded up to even, 16-B aligned):
+        // 128-bit LDS accesses, conflict-free because the lane stride (20 dwords at p = 10) is 4 x odd.
+        // Software-pipelined: the next column's counts AND state are in flight while this one is computed.
+        {
+            int k = NR + tid;
+            float xn[P];
+            double an[PS];
+            if (k < nLe) {
+                load_x<P>(Fb, S, k, xn);
+                if (t > 0) lds_col_read<PS>(lam + (size_t) (k - NR) * PS, an);
+            }
+#pragma clang loop unroll(disable)
+            for (; k < nLe; k += NT) {
+                double f[P], a[P];
+#pragma unroll
+                for (int i = 0; i < P; i++) { f[i] = (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
+                if (k + NT < nLe) {
+                    load_x<P>(Fb, S, k + NT, xn);
+                    if (t > 0) lds_col_read<PS>(lam + (size_t) (k + NT - NR) * PS, an);
+                }
+                col_step<P>(f, a, u, c, G);
+                double aw[PS];
+#pragma unroll
+                for (int i = 0; i < PS; i++) aw[i] = i < P ? a[i] : 0.0;
+                lds_col_write<PS>(lam + (size_t) (k - NR) * PS, aw);
+            }
+        }
+        // HBM tier (pipelined the same way, state included)
+        {
+            int k = NR + nL + tid;
+            float xn[P];
+            double an[P];
+            if (k < n) {
+                load_x<P>(Fb, S, k, xn);
+                if (t > 0) {
+#pragma unroll
+                    for (int i = 0; i < P; i++) an[i] = Lg[(size_t) i * S + k];
+                }
+            }
+#pragma clang loop unroll(disable)
+            for (; k < n; k += NT) {
+                double f[P], a[P];
+#pragma unroll
+                for (int i = 0; i < P; i++) { f[i] = (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
+                if (k + NT < n) {
+                    load_x<P>(Fb, S, k + NT, xn);
+                    if (t > 0) {
+#pragma unroll
+                        for (int i = 0; i < P; i++) an[i] = Lg[(size_t) i * S + k + NT];
+                    }
+                }
+                col_step<P>(f, a, u, c, G);
+#pragma unroll
+                for (int i = 0; i < P; i++) Lg[(size_t) i * S + k] = a[i];
+            }
+        }
+        DN_T1(0); }
+        { DN_T0(); block_sum_lds<NG, P, NT, gram_t>(G, sm); DN_T1(1); }
+        { DN_T0();
+        steps += top_eig_rows<P>(sm.tot, u, theta);
+#pragma unroll
+        for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
+        DN_T1(2); }
+    }
+
+    // final pass: K E of the last SVD, its row sums, the clamped row sums and the residual profile.
+    double acc[2 * P + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CR; cc++) {
+        const int k = cc * NT + tid;
+        if (k < n) {
+            double f[P], s, r;
+            load_f<P>(Fb, S, k, inv, f);
+            col_final<P>(f, lr[cc], u, first, acc, s, r);
+            rs[k] = r;
+            if (first) sv[k] = s;
+        }
+    }
+#pragma clang loop unroll(disable)
+    for (int k = NR + tid; k < n; k += NT) {
+        double f[P], l[P], s, r;
+        load_f<P>(Fb, S, k, inv, f);
+        if (k < nLe) {
+            double al[PS];
+            lds_col_read<PS>(lam + (size_t) (k - NR) * PS, al);
+#pragma unroll
+            for (int i = 0; i < P; i++) l[i] = al[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; i++) l[i] = Lg[(size_t) i * S + k];
+        }
+        col_final<P>(f, l, u, first, acc, s, r);
+        rs[k] = r;
+        if (first) sv[k] = s;
+    }
+    block_sum_lds<2 * P + 1, P, NT, double>(acc, sm);
+    if (tid < 2 * P + 1) g_gs.sums[tid] = sm.tot[tid];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < P; i++) g_gs.u[i] = u[i];
+        g_gs.theta = theta;
+        g_gs.steps += steps;
+        g_gs.status = ST_OK;
+#ifdef DN_STAMP
+        g_gs.stamp[0] += stamp[0]; g_gs.stamp[1] += stamp[1]; g_gs.stamp[2] += stamp[2];
+#endif
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_baseline: the per-gene state machine.  Gene-level vectors (rho, K, ...) are wave-uniform and live in
+// LDS (GeneState) so that the registers belong to the Gram accumulators and the lambda register tier.
+// ---------------------------------------------------------------------------------------------------
 
 template <int P> __device__ __forceinline__ double lds_max(const double *v)
 { double m = v[0];
@@ -435,19 +776,22 @@ template <int P> __device__ __forceinline__ double lds_min(const double *v)
 #pragma unroll
   for (int i = 1; i < P; i++) { const double t = v[i]; m = t < m ? t : m; } return m; }
 
-template <int P, int NT>
-__global__ __launch_bounds__(NT) void k_baseline(IterArgs A)
+template <int P, int NT, int CR>
+__global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
 {
     constexpr int W = NT / 64;
-    __shared__ Smem<P, NT> sm;
-    __shared__ GeneState<P> gs;
+    Smem<P, NT> &sm = g_sm;
+    GeneState<P> &gs = g_gs;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int S = A.S;
-    double *Fs = A.ws + (size_t) blockIdx.x * A.slot_stride;
-    double *Fb = Fs + (size_t) P * S;
-    double *Lm = Fb + (size_t) P * S;
-    double *sv = Lm + (size_t) P * S;
-    double *rs = sv + S;
+    const int nL = A.lds_cols;
+    char *slot = A.ws + (size_t) blockIdx.x * A.slot_bytes;
+    float *Fs = reinterpret_cast<float *>(slot);                      // pristine compacted raw counts  [P][S]
+    float *Fb = Fs + (size_t) P * S;                                  // working copy after bin drops   [P][S]
+    double *Lg = reinterpret_cast<double *>(Fb + (size_t) P * S);     // x + lambda, HBM tier           [P][S]
+    double *sv = Lg + (size_t) P * S;                                 // s_start                        [S]
+    double *rs = sv + S;                                              // residual profile               [S]
+    if (tid < P) gs.inv[tid] = A.inv_scale[tid];
 
     for (;;) {
         if (tid == 0) sm.gene = atomicAdd(A.counter, 1);
@@ -460,10 +804,12 @@ __global__ __launch_bounds__(NT) void k_baseline(IterArgs A)
         const float *x = A.cov + A.goff[g];
 
         int n0 = 0, n_calls = 0, n_drops = 0, exit_code = EXIT_LOW_COV, loop_reason = LOOP_NOT_ENTERED;
-        int status = ST_OK, flag = 0, steps = 0, emode = EM_INPUT;
+        int status = ST_OK, flag = 0, emode = EM_INPUT;
         long long sum_cols = 0;
+        const long long t_gene0 = __builtin_amdgcn_s_memtime();
         int32_t *tr = A.trace + (size_t) g * TRACE_LEN;
         if (tid < P) { gs.rho[tid] = 0.0; gs.K[tid] = 0.0; gs.us[tid] = 0.0; }
+        if (tid == 0) { gs.steps = 0; gs.stamp[0] = gs.stamp[1] = gs.stamp[2] = 0; }
 
         // ---- get_high_coverage_idx (nmf.py:66-76) on F = x / s (nmf.py:146) -------------------------
         // max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): division by a positive scalar is monotone.
@@ -488,7 +834,8 @@ __global__ __launch_bounds__(NT) void k_baseline(IterArgs A)
         const int seg = ((L + W - 1) / W + 63) & ~63;
         const int jb = w * seg, je = (jb + seg < L) ? jb + seg : L;
 
-        // pass 1: count per wave segment; pass 2: ordered compaction into Fs / Fb (nmf.py:236-238)
+        // pass 1: count per wave segment; pass 2: ordered compaction of the raw counts into Fs / Fb (nmf.py:236-238).
+        // The threshold test uses the true quotient x / s so that ties resolve exactly as in the reference.
         {
             double sumF[P];
 #pragma unroll
@@ -499,11 +846,12 @@ __global__ __launch_bounds__(NT) void k_baseline(IterArgs A)
                 for (int c = jb; c < je; c += 64) {
                     const int j = c + lane;
                     bool hi = false;
+                    float xv[P];
                     double f[P];
                     if (j < je) {
                         double cm = 0.0;
 #pragma unroll
-                        for (int i = 0; i < P; i++) { f[i] = (double) x[(size_t) i * L + j] / A.scale[i]; cm = f[i] > cm ? f[i] : cm; }
+                        for (int i = 0; i < P; i++) { xv[i] = x[(size_t) i * L + j]; f[i] = (double) xv[i] / A.scale[i]; cm = f[i] > cm ? f[i] : cm; }
                         hi = cm > thr;
                         if (ds0 >= 0) hi = hi && (j >= ds0) && ((j - ds0) % rate == 0);   // nmf.py:223-227
                     }
@@ -512,8 +860,8 @@ __global__ __launch_bounds__(NT) void k_baseline(IterArgs A)
                         const int pos = base + run + __popcll(mask & ((1ull << lane) - 1ull));
 #pragma unroll
                         for (int i = 0; i < P; i++) {
-                            Fs[(size_t) i * S + pos] = f[i];
-                            Fb[(size_t) i * S + pos] = f[i];
+                            Fs[(size_t) i * S + pos] = xv[i];
+                            Fb[(size_t) i * S + pos] = xv[i];
                             sumF[i] += f[i];
                         }
                     }
@@ -543,150 +891,157 @@ __global__ __launch_bounds__(NT) void k_baseline(IterArgs A)
         if (n0 >= A.min_hc) {
             if (!(lds_min<P>(gs.sumF) > 0.0)) exit_code = EXIT_ZERO_SAMPLE;            // nmf.py:241
             else {
-                double u[P], theta = 0.0, sums[2 * P + 1];
-                status = nmf_call<P, NT>(Fb, Lm, rs, sv, n, S, A.T, true, sm, u, theta, sums, steps);  // nmf.py:245
-                n_calls = 1; sum_cols = n;
-                if (status == ST_OK) {
-                    if (tid == 0) {
-                        const double sig = sqrt(theta);
-                        gs.sig0 = sig;
+                const double min_gene_len = fmax(2.0, ceil(200.0 * (1.0 / (double) rate)));   // nmf.py:261
+                const double min_bins = ceil((double) A.bins * 0.2);                         // nmf.py:35
+                int csize = 1, n_bins = 0;
+                bool first = true, in_loop = false;
+                // One nmf() call per trip: the first on F_start (nmf.py:245), the others inside the
+                // `while max(rho) > 0.1` loop of nmf.py:273-324 after a bin has been dropped.
+                for (;;) {
+                    nmf_call<P, NT, CR>(Fb, Lg, rs, sv, n, S, nL, A.T, first ? 1 : 0);       // results in gs (LDS)
+                    if (gs.status != ST_OK) { status = gs.status; break; }
+                    const double *u = gs.u, *sums = gs.sums;
+                    const double theta = gs.theta;
+                    n_calls++; sum_cols += n;
+                    if (first) {
+                        if (tid == 0) {
+                            const double sig = sqrt(theta);
+                            gs.sig0 = sig;
 #pragma unroll
-                        for (int i = 0; i < P; i++) {
-                            gs.us[i] = u[i];                                               // nmf.py:250
-                            gs.K[i] = u[i] * sig;
-                            gs.rho[i] = 1.0 - sums[1 + P + i] / (u[i] * sums[0] + 1.0);   // nmf.py:254
-                            gs.rho_fb[i] = 1.0 - gs.sumF[i] / (sums[1 + i] + 1.0);
+                            for (int i = 0; i < P; i++) {
+                                gs.us[i] = u[i];                                               // nmf.py:250
+                                gs.K[i] = u[i] * sig;
+                                gs.rho[i] = 1.0 - sums[1 + P + i] / (u[i] * sums[0] + 1.0);   // nmf.py:254
+                                gs.rho_fb[i] = 1.0 - gs.sumF[i] / (sums[1 + i] + 1.0);
+                            }
                         }
-                    }
-                    __syncthreads();
-                    double med;
-                    {
-                        double om[P];
+                        __syncthreads();
+                        double med;
+                        {
+                            double om[P];
 #pragma unroll
-                        for (int i = 0; i < P; i++) om[i] = 1.0 - gs.rho[i];
-                        med = median_of<P>(om);
-                    }
-                    if (med > 1.0) {                                                   // nmf.py:257
-                        exit_code = EXIT_MEDIAN;
-                    } else {
-                        const double min_gene_len = fmax(2.0, ceil(200.0 * (1.0 / (double) rate)));       // nmf.py:261
-                        const double min_bins = ceil((double) A.bins * 0.2);                             // nmf.py:35
+                            for (int i = 0; i < P; i++) om[i] = 1.0 - gs.rho[i];
+                            med = median_of<P>(om);
+                        }
+                        if (med > 1.0) { exit_code = EXIT_MEDIAN; break; }                              // nmf.py:257
                         emode = (n0 < L) ? EM_EXPAND : EM_RAW;
                         exit_code = EXIT_NO_LOOP;
-                        if ((double) n0 >= min_gene_len && lds_min<P>(gs.rho) <= 0.2 && !A.skip) {      // nmf.py:265
-                            // split_into_chunks(range(n0), bins)   utils.py:176-192, nmf.py:269-271
-                            const int csize = (n0 + A.bins - 1) / A.bins;
-                            int n_bins = (n0 + csize - 1) / csize;
-                            if (tid < n_bins) sm.alive[tid] = tid;
-                            __syncthreads();
-                            while (lds_max<P>(gs.rho) > 0.1) {                                           // nmf.py:273
-                                flag = 1;                                                                // nmf.py:276
-                                loop_reason = LOOP_NATURAL;
-                                // per-bin mean of rs[] (nmf.py:283): one wave per bin, fixed order
-                                for (int b = w; b < n_bins; b += W) {
-                                    const int kb = b * csize, ke = (kb + csize < n) ? kb + csize : n;
-                                    double part = 0.0;
-                                    for (int k = kb + lane; k < ke; k += 64) part += rs[k];
-                                    part = wave_sum1(part);
-                                    if (lane == 0) sm.ss[b] = part / (double) (ke - kb);
-                                }
-                                __syncthreads();
-                                double best = -INFINITY; int drop = 0;
-                                for (int b = 0; b < n_bins; b++) { const double v = sm.ss[b]; if (v > best) { best = v; drop = b; } }   // nmf.py:291
-                                __syncthreads();
-                                if (best == 0.0) { loop_reason = LOOP_PERFECT; break; }                  // nmf.py:286
-                                // drop the bin, renumber (nmf.py:292-302); Fb is rebuilt from the pristine Fs
-                                const int kb = drop * csize;
-                                const int dlen = ((kb + csize < n) ? kb + csize : n) - kb;
-                                if (tid == 0) {
-                                    for (int b = drop; b < n_bins - 1; b++) sm.alive[b] = sm.alive[b + 1];
-                                    if (n_drops < 32) tr[8 + n_drops] = drop;
-                                }
-                                n_bins--;
-                                n -= dlen;
-                                n_drops++;
-                                __syncthreads();
-                                for (int k = tid; k < n; k += NT) {
-                                    const int a = k / csize;
-                                    const int ko = sm.alive[a] * csize + (k - a * csize);
+                        if (!((double) n0 >= min_gene_len && lds_min<P>(gs.rho) <= 0.2 && !A.skip)) break;   // nmf.py:265
+                        in_loop = true;
+                        // split_into_chunks(range(n0), bins)   utils.py:176-192, nmf.py:269-271
+                        csize = (n0 + A.bins - 1) / A.bins;
+                        n_bins = (n0 + csize - 1) / csize;
+                        if (tid < n_bins) sm.alive[tid] = tid;
+                        __syncthreads();
+                        first = false;
+                    } else {
+                        bool zero_row = false;
 #pragma unroll
-                                    for (int i = 0; i < P; i++) Fb[(size_t) i * S + k] = Fs[(size_t) i * S + ko];
-                                }
-                                __syncthreads();
-                                if (n < 2) { loop_reason = LOOP_VALUE_ERROR; break; }                    // svds ValueError, nmf.py:306-310
-                                const int st = nmf_call<P, NT>(Fb, Lm, rs, sv, n, S, A.T, false, sm, u, theta, sums, steps);
-                                if (st != ST_OK) { status = st; break; }
-                                n_calls++; sum_cols += n;
-                                bool zero_row = false;
+                        for (int i = 0; i < P; i++) zero_row = zero_row || (u[i] * sums[0] == 0.0);
+                        if (tid == 0) {
+                            const double sg = sqrt(theta);
 #pragma unroll
-                                for (int i = 0; i < P; i++) zero_row = zero_row || (u[i] * sums[0] == 0.0);
-                                if (tid == 0) {
-                                    const double sg = sqrt(theta);
-#pragma unroll
-                                    for (int i = 0; i < P; i++) {
-                                        gs.K[i] = u[i] * sg;                                             // nmf.py:307
-                                        if (!zero_row) gs.rho[i] = 1.0 - sums[1 + P + i] / (sums[1 + i] + 1.0);   // nmf.py:318-321
-                                    }
-                                }
-                                __syncthreads();
-                                if (zero_row) { loop_reason = LOOP_ZERO_ROWSUM; break; }                 // nmf.py:315
-                                if ((double) n_bins <= min_bins || (double) n < min_gene_len) { loop_reason = LOOP_MIN_BINS; break; }  // nmf.py:323
-                            }
-                            if (status == ST_OK) {
-                                bool fallback = false;
-                                if (lds_max<P>(gs.rho) < 0.2) {                                          // nmf.py:327
-                                    double K[P];
-#pragma unroll
-                                    for (int i = 0; i < P; i++) K[i] = gs.K[i];
-                                    status = fix_k<P>(K);                                                // nmf.py:329-330
-                                    if (status == ST_OK) {
-                                        double se[1] = {0.0};
-                                        for (int k = tid; k < n0; k += NT) {                             // nmf.py:333
-                                            double m = -INFINITY;
-#pragma unroll
-                                            for (int i = 0; i < P; i++) { const double qv = Fs[(size_t) i * S + k] / K[i]; m = qv > m ? qv : m; }
-                                            se[0] += m;
-                                        }
-                                        block_sum<1, P, NT>(se, sm);
-                                        double rmax = -INFINITY;
-#pragma unroll
-                                        for (int i = 0; i < P; i++) {
-                                            const double r = 1.0 - gs.sumF[i] / (K[i] * se[0] + 1.0);     // nmf.py:334-337
-                                            rmax = r > rmax ? r : rmax;
-                                        }
-                                        __syncthreads();
-                                        if (rmax > 0.9) { fallback = true; exit_code = EXIT_REFINE_FALLBACK; }          // nmf.py:342
-                                        else {
-                                            exit_code = EXIT_REFINED; emode = (n0 < L) ? EM_EXPAND : EM_REFINED;
-                                            if (tid == 0) {
-#pragma unroll
-                                                for (int i = 0; i < P; i++) { gs.K[i] = K[i]; gs.rho[i] = 1.0 - gs.sumF[i] / (K[i] * se[0] + 1.0); }
-                                            }
-                                        }
-                                    }
-                                } else { fallback = true; exit_code = EXIT_NOT_FOUND_FALLBACK; }          // nmf.py:349
-                                if (fallback && status == ST_OK) {
-                                    if (tid == 0) {
-#pragma unroll
-                                        for (int i = 0; i < P; i++) { gs.K[i] = gs.us[i] * gs.sig0; gs.rho[i] = gs.rho_fb[i]; }
-                                    }
-                                    emode = (n0 < L) ? EM_EXPAND : EM_CLAMPED;
-                                }
-                                __syncthreads();
+                            for (int i = 0; i < P; i++) {
+                                gs.K[i] = u[i] * sg;                                             // nmf.py:307
+                                if (!zero_row) gs.rho[i] = 1.0 - sums[1 + P + i] / (sums[1 + i] + 1.0);   // nmf.py:318-321
                             }
                         }
-                        // the re-expansion fix-up runs (and may raise) whenever the estimate is narrower than F  nmf.py:358-362
-                        if (status == ST_OK && n0 < L) {
-                            double K[P];
+                        __syncthreads();
+                        if (zero_row) { loop_reason = LOOP_ZERO_ROWSUM; break; }                 // nmf.py:315
+                        if ((double) n_bins <= min_bins || (double) n < min_gene_len) { loop_reason = LOOP_MIN_BINS; break; }  // nmf.py:323
+                    }
+                    if (!(lds_max<P>(gs.rho) > 0.1)) break;                                      // nmf.py:273
+                    flag = 1;                                                                    // nmf.py:276
+                    loop_reason = LOOP_NATURAL;
+                    // per-bin mean of rs[] (nmf.py:283): one wave per bin, fixed order
+                    for (int b = w; b < n_bins; b += W) {
+                        const int kb = b * csize, ke = (kb + csize < n) ? kb + csize : n;
+                        double part = 0.0;
+                        for (int k = kb + lane; k < ke; k += 64) part += rs[k];
+                        part = wave_sum1(part);
+                        if (lane == 0) sm.ss[b] = part / (double) (ke - kb);
+                    }
+                    __syncthreads();
+                    double best = -INFINITY; int drop = 0;
+                    for (int b = 0; b < n_bins; b++) { const double v = sm.ss[b]; if (v > best) { best = v; drop = b; } }   // nmf.py:291
+                    __syncthreads();
+                    if (best == 0.0) { loop_reason = LOOP_PERFECT; break; }                      // nmf.py:286
+                    // drop the bin, renumber (nmf.py:292-302); Fb is rebuilt from the pristine Fs
+                    const int kb = drop * csize;
+                    const int dlen = ((kb + csize < n) ? kb + csize : n) - kb;
+                    if (tid == 0) {
+                        for (int b = drop; b < n_bins - 1; b++) sm.alive[b] = sm.alive[b + 1];
+                        if (n_drops < 32) tr[8 + n_drops] = drop;
+                    }
+                    n_bins--;
+                    n -= dlen;
+                    n_drops++;
+                    __syncthreads();
+                    for (int k = tid; k < n; k += NT) {
+                        const int a = k / csize;
+                        const int ko = sm.alive[a] * csize + (k - a * csize);
 #pragma unroll
-                            for (int i = 0; i < P; i++) K[i] = gs.K[i];
-                            status = fix_k<P>(K);
+                        for (int i = 0; i < P; i++) Fb[(size_t) i * S + k] = Fs[(size_t) i * S + ko];
+                    }
+                    __syncthreads();
+                    if (n < 2) { loop_reason = LOOP_VALUE_ERROR; break; }                        // svds ValueError, nmf.py:306-310
+                }
+
+                if (in_loop && status == ST_OK) {
+                    bool fallback = false;
+                    if (lds_max<P>(gs.rho) < 0.2) {                                              // nmf.py:327
+                        double K[P];
+#pragma unroll
+                        for (int i = 0; i < P; i++) K[i] = gs.K[i];
+                        status = fix_k<P>(K);                                                    // nmf.py:329-330
+                        if (status == ST_OK) {
+                            double se[1] = {0.0};
+                            for (int k = tid; k < n0; k += NT) {                                 // nmf.py:333
+                                double m = -INFINITY;
+#pragma unroll
+                                for (int i = 0; i < P; i++) {
+                                    const double qv = ((double) Fs[(size_t) i * S + k] * gs.inv[i]) / K[i];
+                                    m = qv > m ? qv : m;
+                                }
+                                se[0] += m;
+                            }
+                            block_sum<1, P, NT>(se, sm);
+                            double rmax = -INFINITY;
+#pragma unroll
+                            for (int i = 0; i < P; i++) {
+                                const double r = 1.0 - gs.sumF[i] / (K[i] * se[0] + 1.0);         // nmf.py:334-337
+                                rmax = r > rmax ? r : rmax;
+                            }
                             __syncthreads();
-                            if (tid == 0) {
+                            if (rmax > 0.9) { fallback = true; exit_code = EXIT_REFINE_FALLBACK; }              // nmf.py:342
+                            else {
+                                exit_code = EXIT_REFINED; emode = (n0 < L) ? EM_EXPAND : EM_REFINED;
+                                if (tid == 0) {
 #pragma unroll
-                                for (int i = 0; i < P; i++) gs.K[i] = K[i];
+                                    for (int i = 0; i < P; i++) { gs.K[i] = K[i]; gs.rho[i] = 1.0 - gs.sumF[i] / (K[i] * se[0] + 1.0); }
+                                }
                             }
                         }
+                    } else { fallback = true; exit_code = EXIT_NOT_FOUND_FALLBACK; }              // nmf.py:349
+                    if (fallback && status == ST_OK) {
+                        if (tid == 0) {
+#pragma unroll
+                            for (int i = 0; i < P; i++) { gs.K[i] = gs.us[i] * gs.sig0; gs.rho[i] = gs.rho_fb[i]; }
+                        }
+                        emode = (n0 < L) ? EM_EXPAND : EM_CLAMPED;
+                    }
+                    __syncthreads();
+                }
+                // the re-expansion fix-up runs (and may raise) whenever the estimate is narrower than F  nmf.py:358-362
+                if (status == ST_OK && exit_code >= EXIT_NO_LOOP && n0 < L) {
+                    double K[P];
+#pragma unroll
+                    for (int i = 0; i < P; i++) K[i] = gs.K[i];
+                    status = fix_k<P>(K);
+                    __syncthreads();
+                    if (tid == 0) {
+#pragma unroll
+                        for (int i = 0; i < P; i++) gs.K[i] = K[i];
                     }
                 }
             }
@@ -706,7 +1061,12 @@ __global__ __launch_bounds__(NT) void k_baseline(IterArgs A)
             A.flags[g] = flag;
             A.emode[g] = emode;
             tr[0] = n0; tr[1] = n_calls; tr[2] = (int32_t) sum_cols; tr[3] = exit_code; tr[4] = loop_reason;
-            tr[5] = n_drops; tr[6] = status; tr[7] = steps;
+            tr[5] = n_drops; tr[6] = status; tr[7] = gs.steps;
+#ifdef DN_STAMP
+            // diagnostic build only: kilo-cycles spent in the pass / reduction / eigen-solver / whole gene
+            tr[40] = (int32_t) (gs.stamp[0] >> 10); tr[41] = (int32_t) (gs.stamp[1] >> 10); tr[42] = (int32_t) (gs.stamp[2] >> 10);
+            tr[43] = (int32_t) ((__builtin_amdgcn_s_memtime() - t_gene0) >> 10);
+#endif
         }
         if (A.want_est && (emode == EM_CLAMPED || emode == EM_RAW)) {
             double *dst = A.svec + A.svoff[g];
@@ -724,7 +1084,7 @@ template <int P, int NT>
 __global__ __launch_bounds__(NT) void k_ratio_svd(InitArgs A)
 {
     constexpr int NG = P * (P + 1) / 2;
-    __shared__ Smem<P, NT> sm;
+    Smem<P, NT> &sm = g_sm;
     const int tid = threadIdx.x;
     for (;;) {
         if (tid == 0) sm.gene = atomicAdd(A.counter, 1);
@@ -828,8 +1188,10 @@ __global__ __launch_bounds__(256) void k_estimates(EstArgs A, const int32_t *__r
     }
 }
 
+#endif  // DN_P
+
 // Launchers instantiated per P in dn_inst.hip ---------------------------------------------------------
-typedef void (*baseline_launch_fn)(const IterArgs &, int grid, hipStream_t);
+typedef int (*baseline_launch_fn)(const IterArgs &, int grid, size_t dyn_lds_bytes, hipStream_t);
 typedef void (*init_launch_fn)(const InitArgs &, int grid, hipStream_t);
 typedef void (*est_launch_fn)(const EstArgs &, const int32_t *, const int32_t *, int n_tiles, hipStream_t);
 typedef int (*occupancy_fn)(int which);
@@ -840,8 +1202,9 @@ struct KernelSet {
     baseline_launch_fn baseline;
     init_launch_fn init;
     est_launch_fn est;
-    occupancy_fn blocks_per_cu;       // which: 0 baseline, 1 init
-    size_t slot_doubles_per_col;      // scratch doubles per column of stride S
+    occupancy_fn blocks_per_cu;       // which: 0 baseline (no dynamic LDS), 1 init
+    int cr;                           // lambda columns per lane held in registers
+    size_t static_lds_bytes;          // static LDS of k_baseline
     const char *baseline_name;
 };
 

@@ -1,0 +1,34 @@
+"""Diagnostics: run one baseline-selection launch on a config-2 draw and print per-gene counter statistics."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from degnorm_amd import synth, _lib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+cfg = dict(synth.CONFIGS['c2'])
+if len(sys.argv) > 3:
+    cfg['l_min'] = cfg['l_max'] = int(sys.argv[3])
+packed, lengths, reads, cls = synth.synth_packed(cfg['seed'], range(n), cfg['p'], cfg['l_min'], cfg['l_max'])
+dev = _lib.Device(0)
+dev.upload_packed(packed, lengths, cfg['p'])
+est, cov, st = dev.ratio_svd_sums()
+scale = np.ones(cfg['p'])
+for rep in range(2):
+    rho, flags, tr = dev.baseline_iteration(scale, nmf_iter=T)
+    print('launch ms', dev.last_kernel_ms())
+calls = tr[:, 1].astype(float); cols = tr[:, 2].astype(float); steps = tr[:, 7].astype(float)
+solves = calls * (T + 1)
+print('genes', n, 'calls/gene', calls.mean(), 'sum cols/gene', cols.mean(), 'mean n per call', cols.sum() / calls.sum())
+print('power steps per solve', steps.sum() / solves.sum(), 'max per gene avg', (steps[solves > 0] / solves[solves > 0]).max())
+print('inner iterations total', solves.sum(), ' col-iters total %.3e' % (cols.sum() * T))
+ms = dev.last_kernel_ms()
+print('ns per inner iteration per CU (256 CUs): %.1f' % (ms * 1e6 * 256 / solves.sum()))
+n0 = tr[:, 0]
+print('n0 quantiles', np.percentile(n0, [10, 50, 90, 99]), 'frac cols beyond 2813:', np.maximum(n0 - 2813, 0).sum() / n0.sum())
+print('exit codes', np.bincount(tr[:, 3], minlength=7), 'loop reasons', np.bincount(tr[:, 4], minlength=6))
+if tr[:, 40:44].any():
+    st = tr[:, 40:44].astype(float).sum(axis=0) * 1024
+    print('stamps (cycles): pass %.3e  reduce %.3e  eigen %.3e  gene total %.3e' % tuple(st))
+    print('per inner iteration: pass %.0f reduce %.0f eigen %.0f ; gene total per inner it %.0f' % tuple(st / (calls * T).sum()))
+    print('pass cycles per column-per-lane: %.0f' % (st[0] / (cols.sum() * T / 256.)))
