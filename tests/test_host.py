@@ -1,0 +1,136 @@
+"""
+CPU-side tests (-m "not gpu"): the C ABI loads and exports every symbol of include/degnorm_amd.h, the host
+mirror keeps the reference's constructor / error behaviour, helpers keep the reference's semantics, the
+result writer produces the reference's files, and the product refuses to run without the HIP device.
+"""
+import ctypes
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_header_symbol():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    from degnorm_amd import _lib, build
+    build.build_library()                      # hipcc cross-compiles gfx950 without a GPU
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = ge.header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), 'missing C ABI symbol ' + s
+    lib.dn_version.restype = ctypes.c_char_p
+    assert b'degnorm_amd' in lib.dn_version()
+    # no compute without a GPU: only queries
+    for p in range(2, 13):
+        assert lib.dn_p_supported(p) == 1
+    assert lib.dn_p_supported(1) == 0 and lib.dn_p_supported(50) == 0
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a HIP device, opening a Device raises (and names the reason)."""
+    from degnorm_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip('a GPU is visible here')
+    with pytest.raises(_lib.DegnormAmdError, match='no HIP device'):
+        _lib.Device(0)
+    from collections import OrderedDict
+    from degnorm_amd.nmf import GeneNMFOA
+    cov = OrderedDict(a=np.ones((3, 300)), b=np.ones((3, 260)))
+    with pytest.raises(_lib.DegnormAmdError):
+        GeneNMFOA(degnorm_iter=1).run(cov, np.ones((2, 3)))
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under degnorm_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'degnorm_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text and 'liboracle' not in text, f
+
+
+def test_constructor_normalisation_matches_reference():
+    """GeneNMFOA.__init__ rules (nmf.py:30-53): abs/int, min_high_coverage >= 2 and forced to 2 when downsampling."""
+    from degnorm_amd.nmf import GeneNMFOA
+    m = GeneNMFOA(degnorm_iter=-3.7, nmf_iter='40', bins=-10, min_high_coverage=1, n_jobs=-2)
+    assert (m.degnorm_iter, m.nmf_iter, m.bins, m.min_high_coverage, m.n_jobs) == (3, 40, 10, 2, 2)
+    assert m.min_bins == 2.0 and m.downsample_rate == 1 and m.fitted is False
+    assert GeneNMFOA(downsample_rate=20, min_high_coverage=77).min_high_coverage == 2
+    assert GeneNMFOA(min_high_coverage=77).min_high_coverage == 77
+    assert GeneNMFOA.fit is GeneNMFOA.run          # BASELINE.json's `fit` alias
+    d = GeneNMFOA()
+    assert (d.degnorm_iter, d.nmf_iter, d.bins, d.min_high_coverage, d.random_state) == (5, 100, 20, 50, 123)
+
+
+def test_split_into_chunks_semantics():
+    """utils.py:176-192: chunk size ceil(len/n); may return fewer than n chunks."""
+    from degnorm_amd.utils import split_into_chunks, chunk_bounds
+    assert [len(c) for c in split_into_chunks(list(range(201)), 20)] == [11] * 18 + [3]
+    assert [len(c) for c in split_into_chunks(list(range(19)), 20)] == [1] * 19
+    assert [len(c) for c in split_into_chunks(list(range(20000)), 8)] == [2500] * 8
+    assert split_into_chunks(list(range(7)), 3) == [[0, 1, 2], [3, 4, 5], [6]]
+    assert chunk_bounds(7, 3) == [0, 3, 6, 7]
+
+
+def test_synth_generator_is_deterministic_and_shardable():
+    from degnorm_amd import synth
+    a, ca = synth.synth_gene(2, 17, 10)
+    b, cb = synth.synth_gene(2, 17, 10)
+    np.testing.assert_array_equal(a, b)
+    assert ca == cb and a.shape[0] == 10 and 200 <= a.shape[1] <= 5000 and a.min() >= 0
+    assert a.shape[1] == synth.gene_length(2, 17)
+    packed, lengths, reads, cls = synth.synth_packed(2, [5, 17, 3], 10, n_threads=1)
+    assert lengths[1] == a.shape[1]
+    o = int(lengths[0]) * 10
+    np.testing.assert_array_equal(packed[o:o + a.size].reshape(a.shape), a.astype(np.float32))
+    np.testing.assert_array_equal(reads[1], np.round(a.sum(axis=1) / 100.))
+    # integer counts < 2^24: the float32 device copy is exact
+    assert a.max() < 2 ** 24 and np.array_equal(a, a.astype(np.float32).astype(np.float64))
+    # all classes appear in a modest draw
+    _, _, classes = synth.synth_dataset(2, 400, 4, 200, 400)
+    assert set(classes) == set(range(9))
+
+
+def test_save_results_files(tmp_path):
+    """save_results writes the reference's files (nmf.py:603-711): 3 CSVs + per-chromosome pickles."""
+    import pandas as pd
+    from degnorm_amd.nmf import GeneNMFOA
+    m = GeneNMFOA(degnorm_iter=2)
+    m.genes = ['g2', 'g0', 'g1']
+    m.p = 2
+    m.rho = np.array([[0.1, 0.2], [0.3, 0.4], [0.5, 0.6]])
+    m.x_adj = m.rho * 100
+    m.ran_baseline_selection = np.array([[True, False], [False, False], [True, True]])
+    est = [np.full((2, 4), k, dtype=float) for k in range(3)]
+    manifest = pd.DataFrame({'chr': ['chr1', 'chr2', 'chr1', 'chr9'], 'gene': ['g0', 'g1', 'g2', 'zz']})
+    with pytest.raises(ValueError, match='Model not yet fit'):
+        m.save_results(est, manifest, output_dir=str(tmp_path))
+    m.fitted = True
+    with pytest.raises(IOError):
+        m.save_results(est, manifest, output_dir=str(tmp_path / 'missing'))
+    with pytest.raises(ValueError, match='columns `chr` and `gene`'):
+        m.save_results(est, manifest[['gene']], output_dir=str(tmp_path))
+    with pytest.raises(ValueError, match='sample IDs'):
+        m.save_results(est, manifest, output_dir=str(tmp_path), sample_ids=['a'])
+    m.save_results(est, manifest, output_dir=str(tmp_path), sample_ids=['s1', 's2'])
+    di = pd.read_csv(tmp_path / 'degradation_index_scores.csv')
+    assert list(di.columns) == ['chr', 'gene', 's1', 's2']
+    assert list(di.gene) == ['g2', 'g0', 'g1'] and list(di.chr) == ['chr1', 'chr1', 'chr2']
+    np.testing.assert_allclose(di[['s1', 's2']].values, m.rho)
+    adj = pd.read_csv(tmp_path / 'adjusted_read_counts.csv')
+    np.testing.assert_allclose(adj[['s1', 's2']].values, m.x_adj)
+    ran = pd.read_csv(tmp_path / 'ran_baseline_selection.csv')
+    assert list(ran.columns) == ['chr', 'gene', 'iter_0', 'iter_1']
+    assert ran.iter_0.tolist() == [True, False, True]
+    with open(tmp_path / 'chr1' / 'estimated_coverage_matrices_chr1.pkl', 'rb') as f:
+        d = pickle.load(f)
+    assert sorted(d) == ['g0', 'g2'] and d['g2'][0, 0] == 0 and d['g0'][0, 0] == 1
+    with open(tmp_path / 'chr2' / 'estimated_coverage_matrices_chr2.pkl', 'rb') as f:
+        assert list(pickle.load(f)) == ['g1']

@@ -1,0 +1,130 @@
+"""
+N > 1 path on CPU: the gene-sharded outer iteration (degnorm_amd/nmf_mpi.py, counterpart of
+degnorm/nmf_mpi.py:555-863) with world_size 2 over torch.distributed/gloo, and through a bare
+send/recv communicator like the reference's mpi4py duck type.  The per-gene arithmetic comes from the
+oracle-backed stand-in device (tests/_oracle_device.py); what is under test is the sharding, the 3p+1
+all-reduce algebra, the gather order and the rank-0 return value -- checked against the REAL reference's
+golden vectors (tests/golden/mpi.npz: run_gene_nmfoa_mpi on 2 and 3 ranks == GeneNMFOA.run).
+"""
+import os
+import queue
+import sys
+import threading
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from conftest import golden                       # noqa: E402
+from degnorm_amd import synth                     # noqa: E402
+
+
+def _inputs():
+    G = golden('mpi')
+    covs = [synth.synth_gene(int(G['seed']), int(g), int(G['p']), int(G['l_min']), int(G['l_max']))[0]
+            for g in G['gene_ids']]
+    cov_dat = OrderedDict(('gene_%06d' % g, c) for g, c in zip(G['gene_ids'], covs))
+    return G, cov_dat
+
+
+def _gloo_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi, TorchComm
+    from _oracle_device import OracleDevice
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        G, cov_dat = _inputs()
+        comm = TorchComm()
+        res = run_gene_nmfoa_mpi(comm, cov_dat if rank == 0 else None, G['reads'] if rank == 0 else None,
+                                 degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), dev=OracleDevice())
+        if rank == 0:
+            out_q.put({k: (v if k != 'estimates' else {g: e.sum(axis=1) for g, e in v.items()}) for k, v in res.items()})
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_matches_reference_mpi_golden(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out_q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, out_q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = out_q.get(timeout=300)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    G, cov_dat = _inputs()
+    np.testing.assert_allclose(res['rho'], G['mpi2_rho'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res['x_adj'], G['mpi2_x_adj'], rtol=1e-9)
+    np.testing.assert_array_equal(res['ran_baseline_selection'], G['mpi2_flags'])
+    assert list(res['estimates'].keys()) == list(cov_dat.keys())          # original gene order (nmf_mpi.py:855)
+    np.testing.assert_allclose(np.vstack(list(res['estimates'].values())), G['mpi2_est_rowsum'], rtol=1e-9)
+
+
+class _ThreadComm(object):
+    """Bare .size/.rank/.send/.recv/.Barrier communicator (what the reference requires of `comm`)."""
+
+    def __init__(self, size):
+        self.size, self.boxes, self.lock, self.bar = size, {}, threading.Lock(), threading.Barrier(size)
+
+    def view(self, rank):
+        parent = self
+
+        class View(object):
+            size = parent.size
+
+            def __init__(self):
+                self.rank = rank
+
+            def _box(self, s, d, t):
+                with parent.lock:
+                    return parent.boxes.setdefault((s, d, t), queue.Queue())
+
+            def send(self, obj, dest, tag=0):
+                self._box(self.rank, dest, tag).put(obj)
+
+            def recv(self, source, tag=0):
+                return self._box(source, self.rank, tag).get(timeout=300)
+
+            def Barrier(self):
+                parent.bar.wait()
+        return View()
+
+
+def test_three_ranks_send_recv_communicator(oracle):
+    from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi
+    from _oracle_device import OracleDevice
+    G, cov_dat = _inputs()
+    comm = _ThreadComm(3)
+    out = [None] * 3
+
+    def work(r):
+        out[r] = run_gene_nmfoa_mpi(comm.view(r), cov_dat if r == 0 else None, G['reads'] if r == 0 else None,
+                                    degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), dev=OracleDevice())
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert out[1] is None and out[2] is None
+    np.testing.assert_allclose(out[0]['rho'], G['mpi3_rho'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(out[0]['x_adj'], G['mpi3_x_adj'], rtol=1e-9)
+    np.testing.assert_array_equal(out[0]['ran_baseline_selection'], G['mpi3_flags'])
+
+
+def test_single_rank_sharded_equals_single_node(oracle):
+    """LocalComm (size 1) through the sharded driver == the reference's single-node result."""
+    from degnorm_amd.nmf_mpi import ShardedNMFOA
+    from _oracle_device import OracleDevice
+    G, cov_dat = _inputs()
+    eng = ShardedNMFOA(degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), dev=OracleDevice())
+    eng.load(list(cov_dat.values()), G['reads'])
+    eng.run(want_estimates=False)
+    np.testing.assert_allclose(eng.rho, G['single_rho'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(eng.x_adj, G['single_x_adj'], rtol=1e-9)
+    np.testing.assert_array_equal(eng.ran_baseline_selection, G['single_flags'])
