@@ -1,0 +1,88 @@
+// Microbenchmark: a stripped model of the NMF-OA inner pass (state in LDS, 55-entry fp64 Gram in registers) at
+// 1, 2 waves per SIMD, with and without the LDS traffic / the Gram, to see what bounds the real kernel's pass.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+constexpr int P = 10, NG = 55, PS = 10;
+template <int MODE, int NT>   // bit0: LDS state traffic, bit1: Gram, bit2: update math
+__global__ __launch_bounds__(NT) void k(double *out, int cols_per_lane, int iters, int nthreads, const float *Fb = nullptr, int S = 0)
+{
+    extern __shared__ __attribute__((aligned(16))) double lam[];
+    const int tid = threadIdx.x;
+    double G[NG]; for (int i = 0; i < NG; i++) G[i] = 0;
+    double u[P]; for (int i = 0; i < P; i++) u[i] = 0.3 + 0.01 * i;
+    for (int c = 0; c < cols_per_lane; c++) for (int i = 0; i < P; i++) lam[(size_t) (c * nthreads + tid) * PS + i] = 1.0 + tid * 1e-3 + i;
+    __syncthreads();
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        if (MODE & 8) {
+#pragma clang loop unroll(disable)
+            for (int c = 0; c < cols_per_lane; c += 2) {
+                double a[P], b[P];
+                double *ca = lam + (size_t) (c * nthreads + tid) * PS, *cb = lam + (size_t) ((c + 1) * nthreads + tid) * PS;
+                for (int i = 0; i < P; i += 2) { double2 v = *(double2 *) (ca + i); a[i] = v.x; a[i + 1] = v.y; double2 w = *(double2 *) (cb + i); b[i] = w.x; b[i + 1] = w.y; }
+                double sa = 0, sb = 0;
+                for (int i = 0; i < P; i++) { sa = fma(u[i], a[i], sa); sb = fma(u[i], b[i], sb); }
+                for (int i = 0; i < P; i++) {
+                    const double fa = 2.0 + i + c, fb = 3.0 + i + c;
+                    double ra = fma(u[i], sa, -fa), rb = fma(u[i], sb, -fb);
+                    a[i] = fmax(fma(-0.1, ra, a[i]), fa); b[i] = fmax(fma(-0.1, rb, b[i]), fb);
+                }
+                for (int i = 0; i < P; i++) for (int j = 0; j <= i; j++) { double g = G[i * (i + 1) / 2 + j]; g = fma(a[i], a[j], g); g = fma(b[i], b[j], g); G[i * (i + 1) / 2 + j] = g; }
+                for (int i = 0; i < P; i += 2) { *(double2 *) (ca + i) = make_double2(a[i], a[i + 1]); *(double2 *) (cb + i) = make_double2(b[i], b[i + 1]); }
+            }
+        } else
+#pragma clang loop unroll(disable)
+        for (int c = 0; c < cols_per_lane; c++) {
+            double a[P], f[P];
+            double *col = lam + (size_t) (c * nthreads + tid) * PS;
+            if (MODE & 1) { for (int i = 0; i < P; i += 2) { double2 v = *(double2 *) (col + i); a[i] = v.x; a[i + 1] = v.y; } }
+            else { for (int i = 0; i < P; i++) a[i] = G[i] * 1e-9 + 1.0 + i; }
+            if (MODE & 16) { const float *fp = Fb + (size_t) blockIdx.x * P * S + c * nthreads + tid; for (int i = 0; i < P; i++) f[i] = (double) fp[(size_t) i * S] * u[P - 1 - i]; }
+            else for (int i = 0; i < P; i++) f[i] = 2.0 + i + c;
+            if (MODE & 4) {
+                double s = 0; for (int i = 0; i < P; i++) s = fma(u[i], a[i], s);
+                for (int i = 0; i < P; i++) { double res = fma(u[i], s, -f[i]); a[i] = fmax(fma(-0.1, res, a[i]), f[i]); }
+            }
+            if (MODE & 2) { for (int i = 0; i < P; i++) for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = fma(a[i], a[j], G[i * (i + 1) / 2 + j]); }
+            else { for (int i = 0; i < P; i++) G[i] += a[i]; }
+            if (MODE & 1) { for (int i = 0; i < P; i += 2) *(double2 *) (col + i) = make_double2(a[i], a[i + 1]); }
+        }
+        for (int i = 0; i < P; i++) u[i] = u[i] * 0.999 + 1e-12 * G[i];
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0; for (int i = 0; i < NG; i++) s += G[i];
+    if (tid == 0 && blockIdx.x == 0) out[0] = (double) (t1 - t0) / ((double) iters * cols_per_lane);
+    if (s == 1.2345) out[1] = s;
+}
+template <int MODE, int NT> void run1(const char *name, double *d)
+{
+    {
+        const int nthreads = NT;
+        const int total_cols = 1536, cpl = total_cols / nthreads;
+        size_t lds = (size_t) total_cols * PS * 8;
+        hipFuncSetAttribute((const void *) k<MODE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        static float *Fb = nullptr; if (!Fb) { hipMalloc(&Fb, 256ull * P * 2048 * 4); hipMemset(Fb, 0, 256ull * P * 2048 * 4); }
+        hipLaunchKernelGGL((k<MODE, NT>), dim3(256), dim3(nthreads), lds, 0, d, cpl, 50, nthreads, Fb, 2048);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((k<MODE, NT>), dim3(256), dim3(nthreads), lds, 0, d, cpl, 400, nthreads, Fb, 2048);
+        hipEventRecord(e1, 0); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+        printf("%-28s threads=%d cols/lane=%d  ticks per column per wave %.0f   wall per pass over %d cols: %.2f us\n",
+               name, nthreads, cpl, h[0], total_cols, ms * 1e3 / 400);
+    }
+}
+int main()
+{
+    double *d; hipMalloc(&d, 64);
+#define RUN(M, name) run1<M, 256>(name, d); run1<M, 512>(name, d);
+    RUN(7, "LDS + update + Gram")
+    RUN(23, "full + F from L2 (fp32, scaled)")
+    RUN(15, "2-column interleave, full")
+    RUN(6, "update + Gram (no LDS)")
+    RUN(2, "Gram only")
+    RUN(5, "LDS + update (no Gram)")
+    RUN(1, "LDS only")
+    return 0;
+}
