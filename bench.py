@@ -39,6 +39,24 @@ def algorithmic_bytes(trace, lengths, p, nmf_iter):
     return float(4.0 * p * (2.0 * lengths.sum() + (sum_cols * (3.0 * nmf_iter + 3.0)).sum()))
 
 
+def pmc_traffic(kernel_name):
+    """
+    HBM bytes per k_baseline launch from the PMC counters.  bench.py cannot collect PMCs itself: the figure comes
+    from the committed rocprofv3 passes of THIS command (profiles/round1/pmc_traffic.json: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 calibration) and is only reported when the
+    profiled kernel is the one that just ran.
+    """
+    path = os.path.join(ROOT, 'profiles', 'round1', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get('kernel') == kernel_name:
+            return float(d['hbm_bytes_per_launch'])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(cfg, p, nmf_iter, iters, n_sample):
     """The CPU oracle (oracle/, parity-pinned port of the reference) timed on this box's host cores."""
     from oracle import oracle as orc
@@ -63,7 +81,7 @@ def main():
     ap.add_argument('--genes', type=int, default=20000, help='total genes (config 2: 20000)')
     ap.add_argument('--iters', type=int, default=5, help='outer DegNorm iterations per step')
     ap.add_argument('--nmf-iter', type=int, default=100)
-    ap.add_argument('--cpu-sample', type=int, default=96, help='genes in the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=768, help='genes in the CPU-baseline sample (0 = skip)')
     ap.add_argument('--warmup-genes', type=int, default=0, help='0: warm up on the full shard')
     args = ap.parse_args()
 
@@ -144,7 +162,8 @@ def main():
                                    .format(args.genes, p, cfg['l_min'], cfg['l_max'], args.iters, args.nmf_iter),
                        'genes_per_gpu': len(my_genes), 'sharding': 'contiguous gene chunks, 1 all-reduce of 3p+1 f64 per outer iter'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBPS,
+                         'traffic': pmc_traffic(eng.dev.main_kernel_name()) if (world == 1 and args.genes == 20000) else None,
                          'kernel': eng.dev.main_kernel_name(), 'avg_launch_ms': avg_ms,
                          'algorithmic_bytes_per_launch': avg_bytes, 'launches_timed': len(kernel_ms),
                          'note': 'rank-0 shard; HIP events on the library stream around each launch'},

@@ -1,5 +1,6 @@
 // dn_inst.hip -- one translation unit per sample count: hipcc -DDN_P=<p> [-DDN_NT=<threads>] -c dn_inst.hip
 // Instantiates the kernels of dn_kernels.hpp for p = DN_P and exports their launchers as dn_kernel_set_p<DN_P>.
+#include <cstdio>
 #include "dn_kernels.hpp"
 
 #ifndef DN_P
@@ -55,10 +56,12 @@ static int blocks_per_cu(int which)
 
 const KernelSet *DN_CAT(kernel_set_p, DN_P)()
 {
+    static char name[64];
+    snprintf(name, sizeof(name), "k_baseline<%d,%d,%d>", (int) DN_P, (int) DN_NT, (int) (DN_CR));
     static const KernelSet ks = {
         DN_P, DN_NT, launch_baseline, launch_init, launch_est, blocks_per_cu,
         DN_CR, sizeof(Smem<DN_P, DN_NT>) + sizeof(GeneState<DN_P>),
-        "k_baseline<" DN_STR(DN_P) "," DN_STR(DN_NT) "," DN_STR(DN_CR) ">",
+        name,
     };
     return &ks;
 }
