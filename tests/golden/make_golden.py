@@ -281,8 +281,52 @@ def sec_mpi():
     print('mpi done')
 
 
+def sec_warm():
+    """
+    G7: synthetic warm-start directory -> reference load_from_previous (warm_start.py) -> the CLI gene filter
+    (__main__.py:219-247, restated here because degnorm.__main__ needs pysam/HTSeq) -> GeneNMFOA.run ->
+    save_results; the three CSVs it writes are the fixture.
+    """
+    import tempfile
+    import pandas as pd
+    from degnorm.warm_start import load_from_previous
+    seed, n_genes, p, l_min, l_max, minimax = 5, 60, 6, 200, 1500, 5
+    src = tempfile.mkdtemp(prefix='dn_warm_src_')
+    out = tempfile.mkdtemp(prefix='dn_warm_out_')
+    synth.write_warm_start_dir(src, seed=seed, n_genes=n_genes, p=p, l_min=l_min, l_max=l_max)
+    dat = load_from_previous(src, out)
+    gene_cov_dict, read_count_df, genes_df, sample_ids = dat['gene_cov_dict'], dat['read_count_df'], dat['genes_df'], dat['sample_ids']
+    loaded_order = list(gene_cov_dict.keys())
+    delete_idx = []
+    for i in range(genes_df.shape[0]):                                       # __main__.py:223-234
+        gene = genes_df.gene.iloc[i]
+        cov_mat = gene_cov_dict[gene]
+        if (cov_mat.max() < minimax) or (cov_mat.shape[1] <= 1):
+            delete_idx.append(i)
+            del gene_cov_dict[gene]
+    if delete_idx:
+        read_count_df = read_count_df.drop(delete_idx, axis=0).reset_index(drop=True)
+        genes_df = genes_df.drop(delete_idx, axis=0).reset_index(drop=True)
+    m = GeneNMFOA(degnorm_iter=2, nmf_iter=50, downsample_rate=1, n_jobs=1)
+    est = m.run(gene_cov_dict, reads_dat=read_count_df[sample_ids].values.astype(float))
+    m.save_results(est, gene_manifest_df=genes_df, output_dir=out, sample_ids=sample_ids)
+    di = pd.read_csv(os.path.join(out, 'degradation_index_scores.csv'))
+    adj = pd.read_csv(os.path.join(out, 'adjusted_read_counts.csv'))
+    ran = pd.read_csv(os.path.join(out, 'ran_baseline_selection.csv'))
+    import pickle
+    with open(os.path.join(out, 'chr1', 'estimated_coverage_matrices_chr1.pkl'), 'rb') as f:
+        e1 = pickle.load(f)
+    np.savez_compressed(os.path.join(HERE, 'warm.npz'), seed=seed, n_genes=n_genes, p=p, l_min=l_min, l_max=l_max,
+                        minimax=minimax, degnorm_iter=2, nmf_iter=50, sample_ids=np.array(sample_ids),
+                        loaded_order=np.array(loaded_order), genes=di.gene.values.astype(str), chr=di.chr.values.astype(str),
+                        rho=di[sample_ids].values, x_adj=adj[sample_ids].values,
+                        ran=ran[['iter_0', 'iter_1']].values.astype(bool),
+                        chr1_genes=np.array(list(e1.keys())), chr1_est_rowsum=np.vstack([v.sum(axis=1) for v in e1.values()]))
+    print('warm done:', len(loaded_order), 'loaded,', di.shape[0], 'run')
+
+
 SECTIONS = OrderedDict(kat=sec_kat, genes=sec_genes, run_c1=sec_run_c1, run_c2=sec_run_c2, mpi=sec_mpi,
-                       dsamp=sec_dsamp)
+                       dsamp=sec_dsamp, warm=sec_warm)
 
 if __name__ == '__main__':
     import logging

@@ -1,0 +1,76 @@
+"""
+SURVEY 8(f-1)/(f-2), BASELINE config 5 shape: warm-start directory -> CLI gene filter -> NMF-OA core -> result files.
+Golden: tests/golden/warm.npz, produced by the reference's load_from_previous + GeneNMFOA.run + save_results on the same
+synthetic directory (tests/golden/make_golden.py::sec_warm).  The loader/filter test runs on CPU; the end-to-end
+CSV parity test needs the GPU.
+"""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from degnorm_amd import synth
+from degnorm_amd.warm_start import load_from_previous, select_genes, run_from_warm_start
+
+
+def _make_dir(tmp_path, G):
+    src = str(tmp_path / 'prev_run')
+    sample_ids = synth.write_warm_start_dir(src, seed=int(G['seed']), n_genes=int(G['n_genes']), p=int(G['p']),
+                                            l_min=int(G['l_min']), l_max=int(G['l_max']))
+    assert sample_ids == list(G['sample_ids'])
+    return src
+
+
+def test_loader_and_gene_filter_match_reference(tmp_path):
+    G = golden('warm')
+    src = _make_dir(tmp_path, G)
+    new = tmp_path / 'new_run'
+    new.mkdir()
+    dat = load_from_previous(src, str(new))
+    # gene order = per-chromosome pickle order restricted to genes known to both tables (warm_start.py:59-97)
+    assert list(dat['gene_cov_dict'].keys()) == list(G['loaded_order'])
+    assert list(dat['genes_df'].gene) == list(G['loaded_order']) == list(dat['read_count_df'].gene)
+    assert 'ORPHAN_PKL' not in dat['gene_cov_dict'] and dat['sample_ids'] == list(G['sample_ids'])
+    assert (new / 'read_counts.csv').exists() and (new / 'chr2' / 'coverage_matrices_chr2.pkl').exists()
+    cov, reads_df, genes_df = select_genes(dat['gene_cov_dict'], dat['read_count_df'], dat['genes_df'],
+                                           minimax_coverage=int(G['minimax']))
+    assert list(cov.keys()) == list(G['genes']) == list(genes_df.gene) == list(reads_df.gene)
+    assert list(genes_df.chr) == list(G['chr'])
+    with pytest.raises(ValueError, match='No genes available'):
+        d2 = load_from_previous(src)
+        select_genes(d2['gene_cov_dict'], d2['read_count_df'], d2['genes_df'], minimax_coverage=10 ** 9)
+    with pytest.raises(IOError):
+        load_from_previous(src, str(tmp_path / 'does_not_exist'))
+    # MPI-only limits (__main_mpi__.py:374-376)
+    d3 = load_from_previous(src)
+    first = next(iter(d3['gene_cov_dict']))
+    d3['gene_cov_dict'][first] = d3['gene_cov_dict'][first].copy()
+    d3['gene_cov_dict'][first][0, 0] = 2.0 ** 31
+    kept, _, _ = select_genes(d3['gene_cov_dict'], d3['read_count_df'], d3['genes_df'], mpi_limits=True)
+    assert first not in kept
+
+
+@pytest.mark.gpu
+def test_warm_start_end_to_end_csv_parity(tmp_path):
+    """degradation_index_scores.csv / adjusted_read_counts.csv / ran_baseline_selection.csv vs the reference's."""
+    import pandas as pd
+    G = golden('warm')
+    src = _make_dir(tmp_path, G)
+    out = tmp_path / 'out'
+    out.mkdir()
+    run_from_warm_start(src, str(out), degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']),
+                        minimax_coverage=int(G['minimax']))
+    sid = list(G['sample_ids'])
+    di = pd.read_csv(out / 'degradation_index_scores.csv')
+    adj = pd.read_csv(out / 'adjusted_read_counts.csv')
+    ran = pd.read_csv(out / 'ran_baseline_selection.csv')
+    assert list(di.columns) == ['chr', 'gene'] + sid and list(di.gene) == list(G['genes']) and list(di.chr) == list(G['chr'])
+    np.testing.assert_allclose(di[sid].values, G['rho'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(adj[sid].values, G['x_adj'], rtol=1e-9)
+    np.testing.assert_array_equal(ran[['iter_0', 'iter_1']].values.astype(bool), G['ran'])
+    with open(out / 'chr1' / 'estimated_coverage_matrices_chr1.pkl', 'rb') as f:
+        e1 = pickle.load(f)
+    assert list(e1.keys()) == list(G['chr1_genes'])
+    np.testing.assert_allclose(np.vstack([v.sum(axis=1) for v in e1.values()]), G['chr1_est_rowsum'], rtol=1e-9)
