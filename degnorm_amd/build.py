@@ -58,6 +58,11 @@ def build_library(force=False, verbose=False):
         objs.append(o)
         if force or _newer(o, [inst] + hdr):
             jobs.append([hipcc] + FLAGS + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(NT), '-c', inst, '-o', o])
+    gen = os.path.join(CSRC, 'dn_generic.hip')
+    o_gen = os.path.join(OBJ, 'dn_generic.o')
+    objs.append(o_gen)
+    if force or _newer(o_gen, [gen] + hdr):
+        jobs.append([hipcc] + FLAGS + ['-c', gen, '-o', o_gen])
     api = os.path.join(CSRC, 'dn_api.hip')
     o_api = os.path.join(OBJ, 'dn_api.o')
     objs.append(o_api)

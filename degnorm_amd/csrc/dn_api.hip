@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -23,11 +24,15 @@ DN_FOR_EACH_P(DN_DECL)
 
 const KernelSet *kernel_set_for(int p)
 {
+    // DN_FORCE_GENERIC=1 routes every supported p through the run-time-p kernels (used by the tests to
+    // cross-check the two kernel families on the same inputs)
+    const char *force = getenv("DN_FORCE_GENERIC");
+    if (force && force[0] == '1' && p >= 2 && p <= P_MAX) return kernel_set_generic();
     switch (p) {
 #define DN_CASE(P) case P: return kernel_set_p##P();
         DN_FOR_EACH_P(DN_CASE)
 #undef DN_CASE
-        default: return nullptr;
+        default: return (p > 12 && p <= P_MAX) ? kernel_set_generic() : nullptr;
     }
 }
 }  // namespace dn
@@ -200,8 +205,8 @@ static int finish_upload(dn_handle h, const float *host_packed)
     if (per_cu < 1) per_cu = 1;
     h->slots = (int) std::min<int64_t>(n, (int64_t) per_cu * h->n_cus);
     h->S = (h->lmax + 63) & ~63;
-    // slot: Fs, Fb (fp32 [p][S]) + x + lambda spill (fp64 [p][S]) + s_start, residual profile (fp64 [S])
-    h->slot_bytes = (int64_t) h->S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 2 * sizeof(double));
+    // slot: Fs, Fb (fp32 [p][S]) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
+    h->slot_bytes = (int64_t) h->S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double));
     HIP_TRY(hipMalloc(&h->d_ws, (size_t) h->slot_bytes * (size_t) std::max(h->slots, 1)));
     // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
     {
@@ -294,9 +299,11 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     dn::InitArgs a;
     a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.order = h->d_order; a.counter = h->d_counter;
     a.est_sums = h->d_est_sums; a.cov_sums = h->d_cov_sums; a.status = h->d_status; a.n_genes = (int32_t) h->n;
+    a.p = h->p; a.ws = h->d_ws; a.slot_bytes = h->slot_bytes; a.S = h->S;
     HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * 4, h->stream));
     int per_cu = std::max(1, h->ks->blocks_per_cu(1));
-    const int grid = (int) std::min<int64_t>(h->n, (int64_t) per_cu * h->n_cus);
+    int grid = (int) std::min<int64_t>(h->n, (int64_t) per_cu * h->n_cus);
+    if (h->ks->p == 0) grid = std::min(grid, h->slots);          // generic kernels work in the scratch slots
     h->ks->init(a, grid, h->stream);
     HIP_TRY(hipGetLastError());
     const size_t np = (size_t) h->n * h->p;
@@ -338,7 +345,7 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     a.ds_start = nullptr;
     a.ws = h->d_ws; a.rho = h->d_rho; a.flags = h->d_flags; a.trace = h->d_trace; a.kfin = h->d_kfin; a.emode = h->d_emode;
     a.svec = h->d_svec; a.svoff = h->d_svoff; a.slot_bytes = h->slot_bytes; a.n_genes = (int32_t) h->n; a.S = h->S;
-    a.lds_cols = h->lds_cols;
+    a.lds_cols = h->lds_cols; a.p = h->p;
     a.T = prm->nmf_iter; a.bins = prm->bins; a.min_hc = prm->min_high_coverage; a.rate = prm->downsample_rate;
     a.skip = prm->skip_baseline_selection ? 1 : 0; a.want_est = prm->want_estimates ? 1 : 0;
     for (int i = 0; i < h->p; i++) { a.scale[i] = scale[i]; a.inv_scale[i] = 1.0 / scale[i]; h->last_scale[i] = scale[i]; }
@@ -375,7 +382,7 @@ int dn_fetch_estimates(dn_handle h, double *out)
     dn::EstArgs a;
     std::memset(&a, 0, sizeof(a));
     a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.kfin = h->d_kfin; a.emode = h->d_emode;
-    a.svec = h->d_svec; a.svoff = h->d_svoff; a.out = h->d_est; a.n_genes = (int32_t) h->n;
+    a.svec = h->d_svec; a.svoff = h->d_svoff; a.out = h->d_est; a.n_genes = (int32_t) h->n; a.p = h->p;
     for (int i = 0; i < dn::P_MAX; i++) a.scale[i] = i < h->p ? h->last_scale[i] : 1.0;
     h->ks->est(a, h->d_tile_gene, h->d_tile_col, (int) h->n_tiles, h->stream);
     HIP_TRY(hipGetLastError());

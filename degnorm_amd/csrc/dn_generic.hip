@@ -1,0 +1,539 @@
+// dn_generic.hip -- run-time-p variants of the kernels for sample counts above the register-resident range
+// (12 < p <= 64; BASELINE config 4 is p = 50 with take-every 500, active matrices 50 x <= 10).
+//
+// Same state machine and outputs as k_baseline<P,...> (dn_kernels.hpp; reference nmf.py:189-372), but the
+// p x p Gram matrix no longer fits in registers, so the top singular vector of x + lambda is found by power
+// iteration on A A^T applied as two passes (s = A^T u per column, y = A s in row tiles of 8 through the block
+// reduction), with the x + lambda state in the workgroup's scratch slot (L2-resident).  For p > 24 this is also
+// cheaper than forming the Gram (2 p n per step against p^2 n / 2).  When n < p (the down-sampled regime) the
+// same iteration converges to the same top singular triplet; scipy switches to the n x n Gram there, the result
+// is the identical rank-1 factor.  This path is about coverage of the interface, not about speed.
+#include <cstdio>
+#define DN_P 8          // sizes the shared reduction scratch only (Smem<8, 256>)
+#define DN_NT 256
+#include "dn_kernels.hpp"
+
+namespace dn {
+namespace gen {
+
+constexpr int GP = P_MAX;       // 64
+constexpr int NT = 256;
+constexpr int TI = 8;           // rows per reduction tile
+
+struct GState {
+    double scale[GP], inv[GP], sumF[GP], rho[GP], K[GP], us[GP], rho_fb[GP], u[GP], y[GP], csum[GP], rsum[GP];
+    double S, theta, sig0;
+    int32_t status, steps;
+};
+__shared__ GState g_st;
+
+__device__ __forceinline__ void tile_sum(double (&part)[TI])          // totals left in g_sm.tot[0..TI)
+{
+    block_sum_lds<TI, DN_P, NT, double>(part, g_sm);
+}
+
+// y = A (A^T u) with the current u; returns ||y||^2 (every thread) and leaves y in g_st.y.  sj receives A^T u.
+__device__ __forceinline__ double apply_gram(const double *A, double *sj, int n, int S, int p)
+{
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n; k += NT) {
+        double s = 0.0;
+        for (int i = 0; i < p; i++) s = fma(g_st.u[i], A[(size_t) i * S + k], s);
+        sj[k] = s;
+    }
+    for (int i0 = 0; i0 < p; i0 += TI) {
+        double part[TI];
+#pragma unroll
+        for (int r = 0; r < TI; r++) part[r] = 0.0;
+        for (int k = tid; k < n; k += NT) {
+            const double s = sj[k];
+#pragma unroll
+            for (int r = 0; r < TI; r++)
+                if (i0 + r < p) part[r] = fma(A[(size_t) (i0 + r) * S + k], s, part[r]);
+        }
+        tile_sum(part);
+        if (tid < TI && i0 + tid < p) g_st.y[i0 + tid] = g_sm.tot[tid];
+        __syncthreads();
+    }
+    double n2 = 0.0;
+    for (int i = 0; i < p; i++) n2 = fma(g_st.y[i], g_st.y[i], n2);
+    return n2;
+}
+
+// Power iteration on A A^T from the current g_st.u to fp64 round-off (the reference's svds is tol = 0).
+__device__ __forceinline__ int top_singular(const double *A, double *sj, int n, int S, int p)
+{
+    const int tid = threadIdx.x;
+    for (int it = 0; it < 20000; it++) {
+        const double n2 = apply_gram(A, sj, n, S, p);
+        if (tid == 0) g_st.steps++;
+        if (!(n2 > 0.0)) return ST_ARPACK;
+        const double inv = 1.0 / sqrt(n2);
+        double d2 = 0.0;
+        for (int i = 0; i < p; i++) { const double d = g_st.y[i] * inv - g_st.u[i]; d2 = fma(d, d, d2); }
+        __syncthreads();
+        if (tid < p) g_st.u[tid] = g_st.y[tid] * inv;
+        if (tid == 0) g_st.theta = sqrt(n2);              // ||A A^T u|| -> sigma^2 (error second order in the residual)
+        __syncthreads();
+        if (d2 <= 1e-27) break;
+    }
+    return ST_OK;
+}
+
+// One nmf() call (nmf.py:78-107) on Fb (raw counts of the active columns); results in g_st.
+__device__ __attribute__((noinline)) void nmf_gen(const float *Fb, double *A, double *rs, double *sv, double *sj,
+                                                   int n, int S, int T, int first_i, int p)
+{
+    const int tid = threadIdx.x;
+    const bool first = first_i != 0;
+    for (int k = tid; k < n; k += NT)                                    // lmbda = 0: state a = x
+        for (int i = 0; i < p; i++) A[(size_t) i * S + k] = (double) Fb[(size_t) i * S + k] * g_st.inv[i];
+    if (tid < p) g_st.u[tid] = 1.0 / sqrt((double) p);
+    __syncthreads();
+    int st = top_singular(A, sj, n, S, p);                                // SVD of x (nmf.py:88)
+    const double c = 1.0 / sqrt((double) T);
+    for (int t = 0; t < T && st == ST_OK; t++) {
+        for (int k = tid; k < n; k += NT) {
+            double s = 0.0;
+            for (int i = 0; i < p; i++) s = fma(g_st.u[i], A[(size_t) i * S + k], s);
+            for (int i = 0; i < p; i++) {
+                const double f = (double) Fb[(size_t) i * S + k] * g_st.inv[i];
+                const double a = A[(size_t) i * S + k];
+                A[(size_t) i * S + k] = fmax(fma(-c, fma(g_st.u[i], s, -f), a), f);     // nmf.py:94-97
+            }
+        }
+        __syncthreads();
+        st = top_singular(A, sj, n, S, p);
+    }
+    if (st != ST_OK) { if (tid == 0) g_st.status = st; __syncthreads(); return; }
+    // final pass: K E, its row sums, the clamped row sums, the residual profile
+    double accS[TI];
+#pragma unroll
+    for (int r = 0; r < TI; r++) accS[r] = 0.0;
+    for (int k = tid; k < n; k += NT) {
+        double s = 0.0;
+        for (int i = 0; i < p; i++) s = fma(g_st.u[i], A[(size_t) i * S + k], s);
+        sj[k] = s;
+        accS[0] += s;
+        double rmax = 0.0;
+        for (int i = 0; i < p; i++) {
+            const double f = (double) Fb[(size_t) i * S + k] * g_st.inv[i];
+            double d = g_st.u[i] * s - f;
+            if (!first) d = d < 0.0 ? 0.0 : d;
+            const double r = d / (f + 1.0);                                             // nmf.py:282
+            rmax = r * r > rmax ? r * r : rmax;
+        }
+        rs[k] = rmax;
+        if (first) sv[k] = s;
+    }
+    tile_sum(accS);
+    if (tid == 0) g_st.S = g_sm.tot[0];
+    __syncthreads();
+    for (int i0 = 0; i0 < p; i0 += TI) {
+        double pc[TI], pf[TI];
+#pragma unroll
+        for (int r = 0; r < TI; r++) { pc[r] = 0.0; pf[r] = 0.0; }
+        for (int k = tid; k < n; k += NT) {
+            const double s = sj[k];
+#pragma unroll
+            for (int r = 0; r < TI; r++) {
+                if (i0 + r < p) {
+                    const double f = (double) Fb[(size_t) (i0 + r) * S + k] * g_st.inv[i0 + r];
+                    const double ke = g_st.u[i0 + r] * s;
+                    pc[r] += ke < f ? f : ke;                                             // nmf.py:318
+                    pf[r] += f;
+                }
+            }
+        }
+        tile_sum(pc);
+        if (tid < TI && i0 + tid < p) g_st.csum[i0 + tid] = g_sm.tot[tid];
+        __syncthreads();
+        tile_sum(pf);
+        if (tid < TI && i0 + tid < p) g_st.rsum[i0 + tid] = g_sm.tot[tid];
+        __syncthreads();
+    }
+    if (tid == 0) g_st.status = ST_OK;
+    __syncthreads();
+}
+
+__device__ __forceinline__ double st_max(const double *v, int p) { double m = v[0]; for (int i = 1; i < p; i++) m = v[i] > m ? v[i] : m; return m; }
+__device__ __forceinline__ double st_min(const double *v, int p) { double m = v[0]; for (int i = 1; i < p; i++) m = v[i] < m ? v[i] : m; return m; }
+
+// K = abs(K); K[K < 1e-5] = min(K[K >= 1e-5])   nmf.py:329-330, :361-362   (thread 0 only, g_st.K in place)
+__device__ __forceinline__ int fix_k_lds(int p)
+{
+    double mn = INFINITY;
+    for (int i = 0; i < p; i++) { const double k = fabs(g_st.K[i]); if (k >= 1e-5 && k < mn) mn = k; }
+    __syncthreads();
+    if (mn == INFINITY) return ST_EMPTY_MIN;
+    if (threadIdx.x == 0) for (int i = 0; i < p; i++) { const double k = fabs(g_st.K[i]); g_st.K[i] = k < 1e-5 ? mn : k; }
+    return ST_OK;
+}
+
+__global__ __launch_bounds__(NT) void k_baseline_gen(IterArgs A)
+{
+    constexpr int W = NT / 64;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int p = A.p, S = A.S;
+    char *slot = A.ws + (size_t) blockIdx.x * A.slot_bytes;
+    float *Fs = reinterpret_cast<float *>(slot);
+    float *Fb = Fs + (size_t) p * S;
+    double *Ast = reinterpret_cast<double *>(Fb + (size_t) p * S);
+    double *sv = Ast + (size_t) p * S;
+    double *rs = sv + S;
+    double *sj = rs + S;
+    if (tid < p) { g_st.scale[tid] = A.scale[tid]; g_st.inv[tid] = A.inv_scale[tid]; }
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) g_sm.gene = atomicAdd(A.counter, 1);
+        __syncthreads();
+        const int q = g_sm.gene;
+        __syncthreads();
+        if (q >= A.n_genes) break;
+        const int g = A.order[q];
+        const int L = A.glen[g];
+        const float *x = A.cov + A.goff[g];
+        int n0 = 0, n_calls = 0, n_drops = 0, exit_code = EXIT_LOW_COV, loop_reason = LOOP_NOT_ENTERED;
+        int status = ST_OK, flag = 0, emode = EM_INPUT;
+        long long sum_cols = 0;
+        int32_t *tr = A.trace + (size_t) g * TRACE_LEN;
+        if (tid < p) { g_st.rho[tid] = 0.0; g_st.K[tid] = 0.0; g_st.us[tid] = 0.0; }
+        if (tid == 0) g_st.steps = 0;
+        __syncthreads();
+
+        // get_high_coverage_idx (nmf.py:66-76) on F = x / s, true quotients
+        double gm = 0.0;
+        for (int j = tid; j < L; j += NT)
+            for (int i = 0; i < p; i++) { const double f = (double) x[(size_t) i * L + j] / g_st.scale[i]; gm = f > gm ? f : gm; }
+        {
+            for (int o = 32; o >= 1; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
+            if (lane == 0) g_sm.xw[w][0] = gm;
+            __syncthreads();
+            gm = g_sm.xw[0][0];
+            for (int ww = 1; ww < W; ww++) gm = fmax(gm, g_sm.xw[ww][0]);
+            __syncthreads();
+        }
+        const double thr = 0.1 * gm;
+        const int rate = A.rate;
+        const long long ds0 = (rate > 1 && A.ds_start) ? A.ds_start[g] : -1;
+        const int seg = ((L + W - 1) / W + 63) & ~63;
+        const int jb = w * seg, je = (jb + seg < L) ? jb + seg : L;
+        int base = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            int run = 0;
+            for (int cc = jb; cc < je; cc += 64) {
+                const int j = cc + lane;
+                bool hi = false;
+                if (j < je) {
+                    double cm = 0.0;
+                    for (int i = 0; i < p; i++) { const double f = (double) x[(size_t) i * L + j] / g_st.scale[i]; cm = f > cm ? f : cm; }
+                    hi = cm > thr;
+                    if (ds0 >= 0) hi = hi && (j >= ds0) && ((j - ds0) % rate == 0);
+                }
+                const unsigned long long mask = __ballot(hi);
+                if (pass == 1 && hi) {
+                    const int pos = base + run + __popcll(mask & ((1ull << lane) - 1ull));
+                    for (int i = 0; i < p; i++) { const float v = x[(size_t) i * L + j]; Fs[(size_t) i * S + pos] = v; Fb[(size_t) i * S + pos] = v; }
+                }
+                run += __popcll(mask);
+            }
+            if (pass == 0) {
+                if (lane == 0) g_sm.cnt[w] = run;
+                __syncthreads();
+                n0 = 0;
+                for (int ww = 0; ww < W; ww++) { if (ww < w) base += g_sm.cnt[ww]; n0 += g_sm.cnt[ww]; }
+                __syncthreads();
+                if (n0 < A.min_hc) break;
+            }
+        }
+        __syncthreads();
+        int n = n0;
+        if (n0 >= A.min_hc) {
+            // row sums of F_start (true quotients), row tiles of 8
+            for (int i0 = 0; i0 < p; i0 += TI) {
+                double part[TI];
+#pragma unroll
+                for (int r = 0; r < TI; r++) part[r] = 0.0;
+                for (int k = tid; k < n0; k += NT) {
+#pragma unroll
+                    for (int r = 0; r < TI; r++)
+                        if (i0 + r < p) part[r] += (double) Fs[(size_t) (i0 + r) * S + k] / g_st.scale[i0 + r];
+                }
+                tile_sum(part);
+                if (tid < TI && i0 + tid < p) g_st.sumF[i0 + tid] = g_sm.tot[tid];
+                __syncthreads();
+            }
+            if (!(st_min(g_st.sumF, p) > 0.0)) exit_code = EXIT_ZERO_SAMPLE;
+            else {
+                const double min_gene_len = fmax(2.0, ceil(200.0 * (1.0 / (double) rate)));
+                const double min_bins = ceil((double) A.bins * 0.2);
+                int csize = 1, n_bins = 0;
+                bool first = true, in_loop = false;
+                for (;;) {
+                    nmf_gen(Fb, Ast, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    if (g_st.status != ST_OK) { status = g_st.status; break; }
+                    n_calls++; sum_cols += n;
+                    if (first) {
+                        __syncthreads();
+                        if (tid == 0) {
+                            const double sig = sqrt(g_st.theta);
+                            g_st.sig0 = sig;
+                            for (int i = 0; i < p; i++) {
+                                g_st.us[i] = g_st.u[i];
+                                g_st.K[i] = g_st.u[i] * sig;
+                                g_st.rho[i] = 1.0 - g_st.rsum[i] / (g_st.u[i] * g_st.S + 1.0);
+                                g_st.rho_fb[i] = 1.0 - g_st.sumF[i] / (g_st.csum[i] + 1.0);
+                            }
+                        }
+                        __syncthreads();
+                        // nanmedian(1 - rho) > 1   (nmf.py:257): rank selection
+                        double lo = 0.0, hi_v = 0.0;
+                        for (int i = 0; i < p; i++) {
+                            const double vi = 1.0 - g_st.rho[i];
+                            int less = 0, eq = 0;
+                            for (int j2 = 0; j2 < p; j2++) { const double vj = 1.0 - g_st.rho[j2]; less += vj < vi; eq += vj == vi; }
+                            const int r_lo = (p - 1) / 2, r_hi = p / 2;
+                            if (less <= r_lo && r_lo < less + eq) lo = vi;
+                            if (less <= r_hi && r_hi < less + eq) hi_v = vi;
+                        }
+                        if (0.5 * (lo + hi_v) > 1.0) { exit_code = EXIT_MEDIAN; break; }
+                        emode = (n0 < L) ? EM_EXPAND : EM_RAW;
+                        exit_code = EXIT_NO_LOOP;
+                        if (!((double) n0 >= min_gene_len && st_min(g_st.rho, p) <= 0.2 && !A.skip)) break;
+                        in_loop = true;
+                        csize = (n0 + A.bins - 1) / A.bins;
+                        n_bins = (n0 + csize - 1) / csize;
+                        if (tid < n_bins) g_sm.alive[tid] = tid;
+                        __syncthreads();
+                        first = false;
+                    } else {
+                        bool zero_row = false;
+                        for (int i = 0; i < p; i++) zero_row = zero_row || (g_st.u[i] * g_st.S == 0.0);
+                        __syncthreads();
+                        if (tid == 0) {
+                            const double sg = sqrt(g_st.theta);
+                            for (int i = 0; i < p; i++) {
+                                g_st.K[i] = g_st.u[i] * sg;
+                                if (!zero_row) g_st.rho[i] = 1.0 - g_st.rsum[i] / (g_st.csum[i] + 1.0);
+                            }
+                        }
+                        __syncthreads();
+                        if (zero_row) { loop_reason = LOOP_ZERO_ROWSUM; break; }
+                        if ((double) n_bins <= min_bins || (double) n < min_gene_len) { loop_reason = LOOP_MIN_BINS; break; }
+                    }
+                    if (!(st_max(g_st.rho, p) > 0.1)) break;
+                    flag = 1;
+                    loop_reason = LOOP_NATURAL;
+                    for (int b = w; b < n_bins; b += W) {
+                        const int kb = b * csize, ke = (kb + csize < n) ? kb + csize : n;
+                        double part = 0.0;
+                        for (int k = kb + lane; k < ke; k += 64) part += rs[k];
+                        part = wave_sum1(part);
+                        if (lane == 0) g_sm.ss[b] = part / (double) (ke - kb);
+                    }
+                    __syncthreads();
+                    double best = -INFINITY; int drop = 0;
+                    for (int b = 0; b < n_bins; b++) { const double v = g_sm.ss[b]; if (v > best) { best = v; drop = b; } }
+                    __syncthreads();
+                    if (best == 0.0) { loop_reason = LOOP_PERFECT; break; }
+                    const int kb = drop * csize;
+                    const int dlen = ((kb + csize < n) ? kb + csize : n) - kb;
+                    if (tid == 0) {
+                        for (int b = drop; b < n_bins - 1; b++) g_sm.alive[b] = g_sm.alive[b + 1];
+                        if (n_drops < 32) tr[8 + n_drops] = drop;
+                    }
+                    n_bins--; n -= dlen; n_drops++;
+                    __syncthreads();
+                    for (int k = tid; k < n; k += NT) {
+                        const int a = k / csize;
+                        const int ko = g_sm.alive[a] * csize + (k - a * csize);
+                        for (int i = 0; i < p; i++) Fb[(size_t) i * S + k] = Fs[(size_t) i * S + ko];
+                    }
+                    __syncthreads();
+                    if (n < 2) { loop_reason = LOOP_VALUE_ERROR; break; }
+                }
+
+                if (in_loop && status == ST_OK) {
+                    bool fallback = false;
+                    if (st_max(g_st.rho, p) < 0.2) {
+                        __syncthreads();
+                        status = fix_k_lds(p);
+                        __syncthreads();
+                        if (status == ST_OK) {
+                            double se[TI];
+#pragma unroll
+                            for (int r = 0; r < TI; r++) se[r] = 0.0;
+                            for (int k = tid; k < n0; k += NT) {
+                                double m = -INFINITY;
+                                for (int i = 0; i < p; i++) { const double qv = ((double) Fs[(size_t) i * S + k] * g_st.inv[i]) / g_st.K[i]; m = qv > m ? qv : m; }
+                                se[0] += m;
+                            }
+                            tile_sum(se);
+                            const double sE = g_sm.tot[0];
+                            double rmax = -INFINITY;
+                            for (int i = 0; i < p; i++) { const double r = 1.0 - g_st.sumF[i] / (g_st.K[i] * sE + 1.0); rmax = r > rmax ? r : rmax; }
+                            __syncthreads();
+                            if (rmax > 0.9) { fallback = true; exit_code = EXIT_REFINE_FALLBACK; }
+                            else {
+                                exit_code = EXIT_REFINED; emode = (n0 < L) ? EM_EXPAND : EM_REFINED;
+                                if (tid == 0) for (int i = 0; i < p; i++) g_st.rho[i] = 1.0 - g_st.sumF[i] / (g_st.K[i] * sE + 1.0);
+                            }
+                        }
+                    } else { fallback = true; exit_code = EXIT_NOT_FOUND_FALLBACK; }
+                    if (fallback && status == ST_OK) {
+                        __syncthreads();
+                        if (tid == 0) for (int i = 0; i < p; i++) { g_st.K[i] = g_st.us[i] * g_st.sig0; g_st.rho[i] = g_st.rho_fb[i]; }
+                        emode = (n0 < L) ? EM_EXPAND : EM_CLAMPED;
+                    }
+                    __syncthreads();
+                }
+                if (status == ST_OK && exit_code >= EXIT_NO_LOOP && n0 < L) {
+                    __syncthreads();
+                    status = fix_k_lds(p);
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        const bool zero_out = (status != ST_OK) || exit_code <= EXIT_MEDIAN;
+        if (zero_out) { emode = EM_INPUT; if (status != ST_OK) flag = 0; }
+        if (tid < p) {
+            A.rho[(size_t) g * p + tid] = zero_out ? 0.0 : g_st.rho[tid];
+            A.kfin[(size_t) g * p + tid] = (emode == EM_CLAMPED || emode == EM_RAW) ? g_st.us[tid] : g_st.K[tid];
+        }
+        if (tid == 0) {
+            A.flags[g] = flag; A.emode[g] = emode;
+            tr[0] = n0; tr[1] = n_calls; tr[2] = (int32_t) sum_cols; tr[3] = exit_code; tr[4] = loop_reason;
+            tr[5] = n_drops; tr[6] = status; tr[7] = g_st.steps;
+        }
+        if (A.want_est && (emode == EM_CLAMPED || emode == EM_RAW)) {
+            double *dst = A.svec + A.svoff[g];
+            for (int k = tid; k < n0; k += NT) dst[k] = sv[k];
+        }
+        __syncthreads();
+    }
+}
+
+// ratio_svd + row sums (nmf.py:109-121, :524-525) for run-time p; uses the same scratch slots.
+__global__ __launch_bounds__(NT) void k_ratio_svd_gen(InitArgs A)
+{
+    const int tid = threadIdx.x;
+    const int p = A.p, S = A.S;
+    char *slot = A.ws + (size_t) blockIdx.x * A.slot_bytes;
+    double *Ast = reinterpret_cast<double *>(slot + (size_t) 2 * p * S * sizeof(float));
+    double *sj = Ast + (size_t) p * S + 2 * (size_t) S;
+    for (;;) {
+        if (tid == 0) g_sm.gene = atomicAdd(A.counter, 1);
+        __syncthreads();
+        const int q = g_sm.gene;
+        __syncthreads();
+        if (q >= A.n_genes) break;
+        const int g = A.order[q];
+        const int L = A.glen[g];
+        const float *x = A.cov + A.goff[g];
+        int status = ST_OK;
+        if (L < 2) status = ST_VALUE_ERROR;
+        else {
+            for (int k = tid; k < L; k += NT)
+                for (int i = 0; i < p; i++) Ast[(size_t) i * S + k] = (double) x[(size_t) i * L + k];
+            if (tid < p) g_st.u[tid] = 1.0 / sqrt((double) p);
+            if (tid == 0) g_st.steps = 0;
+            __syncthreads();
+            status = top_singular(Ast, sj, L, S, p);
+        }
+        for (int i0 = 0; i0 < p; i0 += TI) {
+            double pe[TI], pc[TI];
+#pragma unroll
+            for (int r = 0; r < TI; r++) { pe[r] = 0.0; pc[r] = 0.0; }
+            if (status == ST_OK) {
+                for (int k = tid; k < L; k += NT) {
+                    double s = 0.0;
+                    for (int i = 0; i < p; i++) s = fma(g_st.u[i], Ast[(size_t) i * S + k], s);
+#pragma unroll
+                    for (int r = 0; r < TI; r++) {
+                        if (i0 + r < p) {
+                            const double v = Ast[(size_t) (i0 + r) * S + k];
+                            const double ke = g_st.u[i0 + r] * s;
+                            pe[r] += ke < v ? v : ke;                         // nmf.py:119
+                            pc[r] += v;
+                        }
+                    }
+                }
+            }
+            tile_sum(pe);
+            if (tid < TI && i0 + tid < p) A.est_sums[(size_t) g * p + i0 + tid] = g_sm.tot[tid];
+            __syncthreads();
+            tile_sum(pc);
+            if (tid < TI && i0 + tid < p) A.cov_sums[(size_t) g * p + i0 + tid] = g_sm.tot[tid];
+            __syncthreads();
+        }
+        if (tid == 0) A.status[g] = status;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_estimates_gen(EstArgs A, const int32_t *__restrict__ tile_gene,
+                                                       const int32_t *__restrict__ tile_col0)
+{
+    const int g = tile_gene[blockIdx.x];
+    const int j = tile_col0[blockIdx.x] + threadIdx.x;
+    const int L = A.glen[g], p = A.p;
+    if (j >= L) return;
+    const float *x = A.cov + A.goff[g];
+    double *o = A.out + A.goff[g];
+    const int em = A.emode[g];
+    const double *K = A.kfin + (size_t) g * p;
+    if (em == EM_INPUT) {
+        for (int i = 0; i < p; i++) o[(size_t) i * L + j] = (double) x[(size_t) i * L + j] / A.scale[i];
+    } else if (em == EM_EXPAND || em == EM_REFINED) {
+        double m = -INFINITY;
+        for (int i = 0; i < p; i++) { const double qv = ((double) x[(size_t) i * L + j] / A.scale[i]) / K[i]; m = qv > m ? qv : m; }
+        for (int i = 0; i < p; i++) {
+            const double f = (double) x[(size_t) i * L + j] / A.scale[i];
+            double v = K[i] * m;
+            if (em == EM_EXPAND) v = v < f ? f : v;
+            o[(size_t) i * L + j] = v;
+        }
+    } else {
+        const double s = A.svec[A.svoff[g] + j];
+        for (int i = 0; i < p; i++) {
+            const double f = (double) x[(size_t) i * L + j] / A.scale[i];
+            double v = K[i] * s;
+            if (em == EM_CLAMPED) v = v < f ? f : v;
+            o[(size_t) i * L + j] = v;
+        }
+    }
+}
+
+static int launch_baseline(const IterArgs &a, int grid, size_t, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_baseline_gen, dim3(grid), dim3(NT), 0, s, a);
+    return (int) hipGetLastError();
+}
+static void launch_init(const InitArgs &a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_ratio_svd_gen, dim3(grid), dim3(NT), 0, s, a); }
+static void launch_est(const EstArgs &a, const int32_t *tg, const int32_t *tc, int n_tiles, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_estimates_gen, dim3(n_tiles), dim3(256), 0, s, a, tg, tc);
+}
+static int blocks_per_cu(int which)
+{
+    int nb = 0;
+    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline_gen, NT, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd_gen, NT, 0);
+    return e == hipSuccess ? nb : 0;
+}
+
+}  // namespace gen
+
+const KernelSet *kernel_set_generic()
+{
+    static const KernelSet ks = {
+        0, gen::NT, gen::launch_baseline, gen::launch_init, gen::launch_est, gen::blocks_per_cu,
+        0, (size_t) 160 * 1024,            // no LDS tier: "static" covers the CU so that lds_cols comes out 0
+        "k_baseline_gen",
+    };
+    return &ks;
+}
+
+}  // namespace dn

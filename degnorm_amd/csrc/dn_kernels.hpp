@@ -32,7 +32,7 @@ namespace dn {
 
 constexpr int TRACE_LEN = 48;
 constexpr int MAX_BINS = 64;
-constexpr int P_MAX = 16;
+constexpr int P_MAX = 64;      // largest sample count any kernel accepts (templated kernels: <= 12; generic: <= 64)
 
 enum { EXIT_LOW_COV = 0, EXIT_ZERO_SAMPLE = 1, EXIT_MEDIAN = 2, EXIT_NO_LOOP = 3,
        EXIT_REFINED = 4, EXIT_REFINE_FALLBACK = 5, EXIT_NOT_FOUND_FALLBACK = 6 };
@@ -66,6 +66,7 @@ struct IterArgs {
     int32_t        S;          // column stride of the scratch arrays (>= longest gene, multiple of 64)
     int32_t        lds_cols;   // lambda columns held in LDS (dynamic shared memory = 8 * p * lds_cols bytes)
     int32_t        T, bins, min_hc, rate, skip, want_est;
+    int32_t        p;          // samples (run-time copy; the templated kernels take it from the template)
     double         scale[P_MAX];
     double         inv_scale[P_MAX];
 };
@@ -80,6 +81,10 @@ struct InitArgs {
     double        *cov_sums;   // n x p
     int32_t       *status;     // n
     int32_t        n_genes;
+    int32_t        p;
+    char          *ws;         // scratch slots (generic kernels only)
+    int64_t        slot_bytes;
+    int32_t        S;
 };
 
 struct EstArgs {
@@ -92,6 +97,7 @@ struct EstArgs {
     const int64_t *svoff;
     double        *out;        // same offsets as cov (goff), float64
     int32_t        n_genes;
+    int32_t        p;
     double         scale[P_MAX];
 };
 
@@ -1209,5 +1215,6 @@ struct KernelSet {
 };
 
 const KernelSet *kernel_set_for(int p);   // dn_api.hip
+const KernelSet *kernel_set_generic();    // dn_generic.hip (run-time p, 12 < p <= P_MAX)
 
 }  // namespace dn

@@ -116,6 +116,19 @@ def test_run_downsampled_vs_reference_golden():
     _check_run(*_run_fixture('run_dsamp50'))
 
 
+def test_run_config4_regime_vs_reference_golden():
+    """BASELINE configs[3] regime: p = 50, take-every 500, active matrices 50 x <= 10 (n < p): run-time-p kernels."""
+    _check_run(*_run_fixture('run_dsamp500'))
+
+
+def test_generic_kernels_agree_with_templated_ones(monkeypatch):
+    """The run-time-p kernel family (dn_generic.hip) on p = 10 and p = 4 inputs: same goldens, same traces."""
+    monkeypatch.setenv('DN_FORCE_GENERIC', '1')
+    _check_run(*_run_fixture('run_c1'))
+    G, m, est = _run_fixture('run_c2')
+    _check_run(G, m, est)
+
+
 def test_input_validation_matches_reference_errors(device):
     from collections import OrderedDict
     from degnorm_amd.nmf import GeneNMFOA

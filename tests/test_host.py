@@ -29,7 +29,8 @@ def test_c_abi_exports_every_header_symbol():
     # no compute without a GPU: only queries
     for p in range(2, 13):
         assert lib.dn_p_supported(p) == 1
-    assert lib.dn_p_supported(1) == 0 and lib.dn_p_supported(50) == 0
+    assert lib.dn_p_supported(50) == 1 and lib.dn_p_supported(64) == 1       # run-time-p kernels
+    assert lib.dn_p_supported(1) == 0 and lib.dn_p_supported(65) == 0
 
 
 def test_product_fails_loudly_without_gpu():
