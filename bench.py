@@ -100,7 +100,8 @@ def main():
 
     torch.cuda.set_device(local_rank)
     comm = LocalComm()
-    if world > 1:
+    distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ     # under torchrun use RCCL even at N = 1
+    if distributed:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         comm = TorchComm(device='cuda:{0}'.format(local_rank))
@@ -142,7 +143,7 @@ def main():
     sync()
     dt = time.time() - t0
 
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -175,7 +176,7 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out))
 
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -16,8 +16,7 @@
 #define DN_STR(a) DN_STR_(a)
 
 #ifndef DN_CR
-#define DN_CR_RAW (40 / DN_P)
-#define DN_CR (DN_CR_RAW < 1 ? 1 : (DN_CR_RAW > 12 ? 12 : DN_CR_RAW))
+#define DN_CR 0        // register-resident tier: measured slower than the LDS tier, kept for experiments
 #endif
 
 namespace dn {

@@ -21,6 +21,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Spill-tier accesses: the x + lambda columns that do not fit on chip are re-read only after a whole pass, far
+// beyond an XCD's L2 share.  The non-temporal forms (DN_SPILL_NT) were measured and did not help (profiles/round1).
+#ifndef DN_SPILL_NT
+#define DN_SPILL_LOAD(p) (*(p))
+#define DN_SPILL_STORE(v, p) (*(p) = (v))
+#else
+#define DN_SPILL_LOAD(p) __builtin_nontemporal_load(p)
+#define DN_SPILL_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 #ifndef DN_GRAM_T
 #define DN_GRAM_T double
 #endif
@@ -640,6 +650,13 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         if (k < n) load_f<P>(Fb, S, k, inv, lr[cc]);
     }
 
+    for (int k = NR + tid; k < nLe; k += NT) {                       // lmbda = zeros (nmf.py:90): state a = x
+        double f[P], a[PS];
+        load_f<P>(Fb, S, k, inv, f);
+#pragma unroll
+        for (int i = 0; i < PS; i++) a[i] = i < P ? f[i] : 0.0;
+        lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
+    }
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
@@ -657,33 +674,27 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             }
         }
         // LDS tier.  Column o keeps its p doubles contiguously (stride PS = p rounded up to even, 16-B aligned):
-        // 128-bit LDS accesses, conflict-free because the lane stride (20 dwords at p = 10) is 4 x odd.
-        // Software-pipelined: the next column's counts AND state are in flight while this one is computed.
+        // 128-bit LDS accesses, conflict-free because the lane stride (20 dwords at p = 10) is 4 x odd.  Deliberately
+        // plain: an explicitly software-pipelined version of this loop (next column's counts and state prefetched into
+        // registers) measured 1.7x SLOWER per column -- the extra live registers end up in AGPRs and every use pays a
+        // copy -- and so did a register-resident tier in front of it (tools/trace_stats.py, profiles/round1).
         {
-            int k = NR + tid;
-            float xn[P];
-            double an[PS];
-            if (k < nLe) {
-                load_x<P>(Fb, S, k, xn);
-                if (t > 0) lds_col_read<PS>(lam + (size_t) (k - NR) * PS, an);
-            }
 #pragma clang loop unroll(disable)
-            for (; k < nLe; k += NT) {
-                double f[P], a[P];
+            for (int k = NR + tid; k < nLe; k += NT) {
+                double f[P], a[PS];
+                load_f<P>(Fb, S, k, inv, f);
+                lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
+                double aa[P];
 #pragma unroll
-                for (int i = 0; i < P; i++) { f[i] = (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
-                if (k + NT < nLe) {
-                    load_x<P>(Fb, S, k + NT, xn);
-                    if (t > 0) lds_col_read<PS>(lam + (size_t) (k + NT - NR) * PS, an);
-                }
-                col_step<P>(f, a, u, c, G);
-                double aw[PS];
+                for (int i = 0; i < P; i++) aa[i] = a[i];
+                col_step<P>(f, aa, u, c, G);
 #pragma unroll
-                for (int i = 0; i < PS; i++) aw[i] = i < P ? a[i] : 0.0;
-                lds_col_write<PS>(lam + (size_t) (k - NR) * PS, aw);
+                for (int i = 0; i < P; i++) a[i] = aa[i];
+                lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
             }
         }
-        // HBM tier (pipelined the same way, state included)
+        // spill tier: x + lambda of the columns that do not fit in LDS lives in the slot (L2 / Infinity Cache).
+        // Here the loads are far away, and prefetching the next column's counts and state does pay (1.15x).
         {
             int k = NR + nL + tid;
             float xn[P];
@@ -692,7 +703,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 load_x<P>(Fb, S, k, xn);
                 if (t > 0) {
 #pragma unroll
-                    for (int i = 0; i < P; i++) an[i] = Lg[(size_t) i * S + k];
+                    for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k]);
                 }
             }
 #pragma clang loop unroll(disable)
@@ -704,12 +715,12 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                     load_x<P>(Fb, S, k + NT, xn);
                     if (t > 0) {
 #pragma unroll
-                        for (int i = 0; i < P; i++) an[i] = Lg[(size_t) i * S + k + NT];
+                        for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k + NT]);
                     }
                 }
                 col_step<P>(f, a, u, c, G);
 #pragma unroll
-                for (int i = 0; i < P; i++) Lg[(size_t) i * S + k] = a[i];
+                for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], &Lg[(size_t) i * S + k]);
             }
         }
         DN_T1(0); }
@@ -747,7 +758,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             for (int i = 0; i < P; i++) l[i] = al[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < P; i++) l[i] = Lg[(size_t) i * S + k];
+            for (int i = 0; i < P; i++) l[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k]);
         }
         col_final<P>(f, l, u, first, acc, s, r);
         rs[k] = r;

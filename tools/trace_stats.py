@@ -32,3 +32,15 @@ if tr[:, 40:44].any():
     print('stamps (cycles): pass %.3e  reduce %.3e  eigen %.3e  gene total %.3e' % tuple(st))
     print('per inner iteration: pass %.0f reduce %.0f eigen %.0f ; gene total per inner it %.0f' % tuple(st / (calls * T).sum()))
     print('pass cycles per column-per-lane: %.0f' % (st[0] / (cols.sum() * T / 256.)))
+if tr[:, 40:44].any():
+    # per-size-class cost of the pass inside the mixed workload
+    ok = (calls > 0)
+    per_col = tr[:, 40].astype(float) * 1024 / np.maximum(cols * T / 256., 1)
+    per_it = (tr[:, 41] + tr[:, 42]).astype(float) * 1024 / np.maximum(calls * T, 1)
+    edges = [0, 500, 1000, 1500, 2000, 2524, 3000, 4000, 6000]
+    print('n0 class: genes, pass ticks per column-per-lane, (reduce+eigen) ticks per inner iteration, share of kernel time')
+    tot = tr[:, 43].astype(float).sum()
+    for a, b in zip(edges[:-1], edges[1:]):
+        m = ok & (n0 >= a) & (n0 < b)
+        if m.any():
+            print('  [%4d,%4d): %5d  %7.0f  %7.0f   %.3f' % (a, b, m.sum(), np.median(per_col[m]), np.median(per_it[m]), tr[m, 43].sum() / tot))
