@@ -29,14 +29,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def algorithmic_bytes(trace, lengths, p, nmf_iter):
+def algorithmic_bytes(trace, lengths, p, nmf_iter, mask=None):
     """
     SURVEY.md 8(d): per gene and outer iteration, fp32 storage, one fused pass per inner NMF-OA iteration that
     reads x and lambda and writes lambda:  bytes_g = 4 p [ L_g + sum_k n_{g,k} (3T + 3) + L_g ],
     with sum_k n_{g,k} (active columns summed over the gene's nmf() calls) taken from the device counters.
+    `mask` selects the genes one kernel processes (the two gene classes run in separate launches).
     """
     sum_cols = trace[:, 2].astype(np.float64)
-    return float(4.0 * p * (2.0 * lengths.sum() + (sum_cols * (3.0 * nmf_iter + 3.0)).sum()))
+    per_gene = 4.0 * p * (2.0 * lengths + sum_cols * (3.0 * nmf_iter + 3.0))
+    return float(per_gene[mask].sum() if mask is not None else per_gene.sum())
 
 
 def pmc_traffic(kernel_name):
@@ -133,13 +135,18 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    kernel_ms, alg_bytes = [], []
+    # dominant kernel = the wide-gene class (genes longer than the split length, one 256-thread workgroup per CU)
+    split = eng.dev.split_length()
+    wide = lengths > split if split > 0 else np.ones(len(lengths), dtype=bool)
+    kernel_ms, alg_bytes, alg_all, narrow_ms = [], [], [], []
     sync()
     t0 = time.time()
     for _ in range(args.steps):
         step()
-        kernel_ms += eng.kernel_ms
-        alg_bytes += [algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in eng.traces]
+        kernel_ms += [c[0] for c in eng.class_ms]
+        narrow_ms += [c[1] for c in eng.class_ms]
+        alg_bytes += [algorithmic_bytes(tr, lengths, p, args.nmf_iter, wide) for tr in eng.traces]
+        alg_all += [algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in eng.traces]
     sync()
     dt = time.time() - t0
 
@@ -164,9 +171,14 @@ def main():
                        'genes_per_gpu': len(my_genes), 'sharding': 'contiguous gene chunks, 1 all-reduce of 3p+1 f64 per outer iter'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
-                         'traffic': pmc_traffic(eng.dev.main_kernel_name()) if (world == 1 and args.genes == 20000) else None,
-                         'kernel': eng.dev.main_kernel_name(), 'avg_launch_ms': avg_ms,
+                         'traffic': pmc_traffic(eng.dev.class_kernel_name(0)) if (world == 1 and args.genes == 20000) else None,
+                         'kernel': eng.dev.class_kernel_name(0), 'avg_launch_ms': avg_ms,
                          'algorithmic_bytes_per_launch': avg_bytes, 'launches_timed': len(kernel_ms),
+                         'genes_in_kernel': int(wide.sum()), 'split_length': split,
+                         'second_kernel': {'kernel': eng.dev.class_kernel_name(1), 'genes': int((~wide).sum()),
+                                           'algorithmic_bytes_per_launch': float(np.mean(alg_all)) - avg_bytes,
+                                           'launch_to_end_ms': float(np.mean(narrow_ms)),
+                                           'note': 'narrow genes, 128-thread workgroups, fills CUs as the wide class drains'},
                          'note': 'rank-0 shard; HIP events on the library stream around each launch'},
             'setup': {'synth_s': t_gen, 'upload_s': t_up},
         }

@@ -59,6 +59,12 @@ def load(build_if_missing=False):
     lib.dn_last_kernel_ms.restype = dbl
     lib.dn_main_kernel_name.argtypes = [vp]
     lib.dn_main_kernel_name.restype = c.c_char_p
+    lib.dn_split_length.argtypes = [vp]
+    lib.dn_split_length.restype = i32
+    lib.dn_class_kernel_ms.argtypes = [vp, c.c_int]
+    lib.dn_class_kernel_ms.restype = dbl
+    lib.dn_class_kernel_name.argtypes = [vp, c.c_int]
+    lib.dn_class_kernel_name.restype = c.c_char_p
     lib.dn_synchronize.argtypes = [vp]
     lib.dn_measure_copy_gbps.argtypes = [vp, i64, c.c_int]
     lib.dn_measure_copy_gbps.restype = dbl
@@ -192,6 +198,15 @@ class Device:
 
     def main_kernel_name(self):
         return self.lib.dn_main_kernel_name(self.h).decode()
+
+    def split_length(self):
+        return int(self.lib.dn_split_length(self.h))
+
+    def class_kernel_ms(self, cls):
+        return float(self.lib.dn_class_kernel_ms(self.h, int(cls)))
+
+    def class_kernel_name(self, cls):
+        return self.lib.dn_class_kernel_name(self.h, int(cls)).decode()
 
     def measure_copy_gbps(self, nbytes=1 << 30, reps=5):
         return float(self.lib.dn_measure_copy_gbps(self.h, int(nbytes), int(reps)))

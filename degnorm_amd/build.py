@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, 'obj')
 LIB = os.path.join(HERE, 'libdegnorm_amd.so')
 P_LIST = list(range(2, 13))          # keep in sync with DN_FOR_EACH_P in csrc/dn_api.hip
 ARCH = 'gfx950'
-NT = int(os.environ.get('DN_NT', '256'))
+NT_LIST = (256, 128)
 EXTRA = ['-D' + d for d in os.environ.get('DN_DEFINES', '').split() if d]   # e.g. DN_DEFINES='DN_CR=2'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on',
          '-Wall', '-Wno-unused-function']
@@ -54,10 +54,11 @@ def build_library(force=False, verbose=False):
     objs = []
     inst = os.path.join(CSRC, 'dn_inst.hip')
     for p in P_LIST:
-        o = os.path.join(OBJ, 'dn_inst_p{0}_nt{1}.o'.format(p, NT))
-        objs.append(o)
-        if force or _newer(o, [inst] + hdr):
-            jobs.append([hipcc] + FLAGS + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(NT), '-c', inst, '-o', o])
+        for nt in NT_LIST:      # wide-gene class (one 256-thread workgroup per CU) and narrow-gene class (two of 128)
+            o = os.path.join(OBJ, 'dn_inst_p{0}_nt{1}.o'.format(p, nt))
+            objs.append(o)
+            if force or _newer(o, [inst] + hdr):
+                jobs.append([hipcc] + FLAGS + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt), '-c', inst, '-o', o])
     gen = os.path.join(CSRC, 'dn_generic.hip')
     o_gen = os.path.join(OBJ, 'dn_generic.o')
     objs.append(o_gen)

@@ -18,9 +18,20 @@
 #define DN_FOR_EACH_P(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 
 namespace dn {
-#define DN_DECL(P) const KernelSet *kernel_set_p##P();
+#define DN_DECL(P) const KernelSet *kernel_set_p##P##_nt256(); const KernelSet *kernel_set_p##P##_nt128();
 DN_FOR_EACH_P(DN_DECL)
 #undef DN_DECL
+
+// 128-thread workgroups (two per CU) for the narrow gene class
+const KernelSet *kernel_set_narrow(int p)
+{
+    switch (p) {
+#define DN_CASE(P) case P: return kernel_set_p##P##_nt128();
+        DN_FOR_EACH_P(DN_CASE)
+#undef DN_CASE
+        default: return nullptr;
+    }
+}
 
 const KernelSet *kernel_set_for(int p)
 {
@@ -29,7 +40,7 @@ const KernelSet *kernel_set_for(int p)
     const char *force = getenv("DN_FORCE_GENERIC");
     if (force && force[0] == '1' && p >= 2 && p <= P_MAX) return kernel_set_generic();
     switch (p) {
-#define DN_CASE(P) case P: return kernel_set_p##P();
+#define DN_CASE(P) case P: return kernel_set_p##P##_nt256();
         DN_FOR_EACH_P(DN_CASE)
 #undef DN_CASE
         default: return (p > 12 && p <= P_MAX) ? kernel_set_generic() : nullptr;
@@ -69,7 +80,7 @@ struct dn_handle_s {
     int32_t *d_order = nullptr;
     int32_t *d_counter = nullptr;
     int64_t *d_ds = nullptr;
-    char    *d_ws = nullptr;
+    char    *d_ws = nullptr;          // alias of cls[0].d_ws
     double  *d_rho = nullptr;
     int32_t *d_flags = nullptr;
     int32_t *d_trace = nullptr;
@@ -83,11 +94,30 @@ struct dn_handle_s {
     int32_t *d_tile_gene = nullptr, *d_tile_col = nullptr;
     int64_t n_tiles = 0;
 
-    int slots = 0;
+    // Gene classes: [0] wide genes on the main kernel set (256-thread workgroups, one per CU, the whole LDS for one
+    // gene), [1] narrow genes (length <= split_len) on 128-thread workgroups, two per CU, so that the serial
+    // reduction / eigen-solver phases of one gene overlap the pass of another.  Each class has its own longest-first
+    // queue, scratch slots and stream; class 0 is launched first and class 1 fills the CUs as they drain.
+    struct GeneClass {
+        const dn::KernelSet *ks = nullptr;
+        int32_t n = 0;
+        int32_t *d_order = nullptr;
+        int32_t *d_counter = nullptr;
+        char *d_ws = nullptr;
+        int slots = 0;
+        int32_t S = 0;
+        int64_t slot_bytes = 0;
+        int32_t lds_cols = 0;
+        size_t dyn_lds = 0;
+        float last_ms = 0.f;
+    };
+    GeneClass cls[2];
+    int32_t split_len = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev2a = nullptr, ev2b = nullptr, ev_ready = nullptr;
+    int slots = 0;              // class 0 (kept for the run-time-p init kernel)
     int32_t S = 0;
     int64_t slot_bytes = 0;
-    int32_t lds_cols = 0;
-    size_t dyn_lds = 0;
     double last_scale[dn::P_MAX] = {0};
     bool have_estimate_state = false;
     float last_ms = 0.f;
@@ -98,7 +128,13 @@ static void free_device(dn_handle h)
     void *ptrs[] = {h->d_cov, h->d_goff, h->d_glen, h->d_order, h->d_counter, h->d_ds, h->d_ws, h->d_rho, h->d_flags,
                     h->d_trace, h->d_kfin, h->d_emode, h->d_svec, h->d_svoff, h->d_est_sums, h->d_cov_sums,
                     h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col};
-    for (void *q : ptrs) if (q) (void) hipFree(q);
+    for (void *q : ptrs) if (q && q != (void *) h->cls[0].d_ws) (void) hipFree(q);
+    for (auto &c : h->cls) {
+        if (c.d_order) (void) hipFree(c.d_order);
+        if (c.d_counter) (void) hipFree(c.d_counter);
+        if (c.d_ws) (void) hipFree(c.d_ws);
+        c = dn_handle_s::GeneClass();
+    }
     h->d_cov = nullptr; h->d_goff = nullptr; h->d_glen = nullptr; h->d_order = nullptr; h->d_counter = nullptr;
     h->d_ds = nullptr; h->d_ws = nullptr; h->d_rho = nullptr; h->d_flags = nullptr; h->d_trace = nullptr;
     h->d_kfin = nullptr; h->d_emode = nullptr; h->d_svec = nullptr; h->d_svoff = nullptr; h->d_est_sums = nullptr;
@@ -135,6 +171,10 @@ int dn_create(int device, dn_handle *out)
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev2a));
+    HIP_TRY(hipEventCreate(&h->ev2b));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     *out = h;
     return DN_OK;
 }
@@ -147,6 +187,10 @@ int dn_destroy(dn_handle h)
     free_device(h);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
+    if (h->ev2a) (void) hipEventDestroy(h->ev2a);
+    if (h->ev2b) (void) hipEventDestroy(h->ev2b);
+    if (h->ev_ready) (void) hipEventDestroy(h->ev_ready);
+    if (h->stream2) (void) hipStreamDestroy(h->stream2);
     if (h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
     return DN_OK;
@@ -200,23 +244,40 @@ static int finish_upload(dn_handle h, const float *host_packed)
     HIP_TRY(hipMemcpyAsync(h->d_tile_col, tc.data(), sizeof(int32_t) * tc.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
 
-    // persistent-workgroup scratch: one slot per resident workgroup
-    int per_cu = h->ks->blocks_per_cu(0);
-    if (per_cu < 1) per_cu = 1;
-    h->slots = (int) std::min<int64_t>(n, (int64_t) per_cu * h->n_cus);
-    h->S = (h->lmax + 63) & ~63;
-    // slot: Fs, Fb (fp32 [p][S]) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
-    h->slot_bytes = (int64_t) h->S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double));
-    HIP_TRY(hipMalloc(&h->d_ws, (size_t) h->slot_bytes * (size_t) std::max(h->slots, 1)));
-    // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
+    // gene classes
     {
-        const int64_t lds_per_block = (160 * 1024) / per_cu - (int64_t) h->ks->static_lds_bytes - 256;
-        const int64_t ps = p + (p & 1);                        // LDS column stride in doubles (16-B aligned)
-        int64_t cols = lds_per_block > 0 ? lds_per_block / (8 * ps) : 0;
-        const int64_t want = std::max<int64_t>(0, (int64_t) h->S - (int64_t) h->ks->cr * h->ks->nt);
-        cols = std::min(cols, want) & ~(int64_t) 1;
-        h->lds_cols = (int32_t) cols;
-        h->dyn_lds = (size_t) cols * 8 * (size_t) ps;
+        const char *env = getenv("DN_SPLIT_LEN");
+        h->split_len = env ? atoi(env) : 2700;     // flat optimum 2300-3200 on config 2 (profiles/round1)
+        const dn::KernelSet *narrow = (h->ks->p != 0) ? dn::kernel_set_narrow(p) : nullptr;
+        if (!narrow) h->split_len = 0;
+        std::vector<int32_t> ord[2];
+        for (int32_t g : order) ord[(h->split_len > 0 && h->glen[g] <= h->split_len) ? 1 : 0].push_back(g);   // stays longest-first
+        h->cls[0].ks = h->ks;
+        h->cls[1].ks = narrow;
+        for (int c = 0; c < 2; c++) {
+            auto &C = h->cls[c];
+            C.n = (int32_t) ord[c].size();
+            if (C.n == 0 || !C.ks) { C.n = 0; continue; }
+            HIP_TRY(hipMalloc(&C.d_order, sizeof(int32_t) * (size_t) C.n));
+            HIP_TRY(hipMalloc(&C.d_counter, sizeof(int32_t) * 4));
+            HIP_TRY(hipMemcpy(C.d_order, ord[c].data(), sizeof(int32_t) * (size_t) C.n, hipMemcpyHostToDevice));
+            int per_cu = C.ks->blocks_per_cu(0);
+            if (per_cu < 1) per_cu = 1;
+            C.slots = (int) std::min<int64_t>(C.n, (int64_t) per_cu * h->n_cus);
+            C.S = (h->glen[ord[c][0]] + 63) & ~63;                    // longest gene of the class
+            // slot: Fs, Fb (fp32 [p][S]) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
+            C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double));
+            HIP_TRY(hipMalloc(&C.d_ws, (size_t) C.slot_bytes * (size_t) std::max(C.slots, 1)));
+            // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
+            const int64_t lds_per_block = (160 * 1024) / per_cu - (int64_t) C.ks->static_lds_bytes - 256;
+            const int64_t ps = p + (p & 1);                        // LDS column stride in doubles (16-B aligned)
+            int64_t cols = lds_per_block > 0 ? lds_per_block / (8 * ps) : 0;
+            cols = std::min<int64_t>(cols, C.S) & ~(int64_t) 1;
+            C.lds_cols = (int32_t) cols;
+            C.dyn_lds = (size_t) cols * 8 * (size_t) ps;
+        }
+        if (h->cls[0].n == 0 && h->cls[1].n > 0 && h->ks->p == 0) return fail(DN_E_STATE, "internal: empty wide class for the generic kernels");
+        h->slots = h->cls[0].slots; h->S = h->cls[0].S; h->slot_bytes = h->cls[0].slot_bytes; h->d_ws = h->cls[0].d_ws;
     }
     return DN_OK;
 }
@@ -345,7 +406,7 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     a.ds_start = nullptr;
     a.ws = h->d_ws; a.rho = h->d_rho; a.flags = h->d_flags; a.trace = h->d_trace; a.kfin = h->d_kfin; a.emode = h->d_emode;
     a.svec = h->d_svec; a.svoff = h->d_svoff; a.slot_bytes = h->slot_bytes; a.n_genes = (int32_t) h->n; a.S = h->S;
-    a.lds_cols = h->lds_cols; a.p = h->p;
+    a.p = h->p;
     a.T = prm->nmf_iter; a.bins = prm->bins; a.min_hc = prm->min_high_coverage; a.rate = prm->downsample_rate;
     a.skip = prm->skip_baseline_selection ? 1 : 0; a.want_est = prm->want_estimates ? 1 : 0;
     for (int i = 0; i < h->p; i++) { a.scale[i] = scale[i]; a.inv_scale[i] = 1.0 / scale[i]; h->last_scale[i] = scale[i]; }
@@ -354,20 +415,31 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
         HIP_TRY(hipMemcpyAsync(h->d_ds, ds_start, sizeof(int64_t) * (size_t) h->n, hipMemcpyHostToDevice, h->stream));
         a.ds_start = h->d_ds;
     }
-    HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * 4, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_trace, 0, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, h->stream));
-    HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    {
-        const int lrc = h->ks->baseline(a, h->slots, h->dyn_lds, h->stream);
+    for (auto &C : h->cls) if (C.n > 0) HIP_TRY(hipMemsetAsync(C.d_counter, 0, sizeof(int32_t) * 4, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_ready, h->stream));
+    for (int c = 0; c < 2; c++) {
+        auto &C = h->cls[c];
+        C.last_ms = 0.f;
+        if (C.n == 0) continue;
+        hipStream_t st = c == 0 ? h->stream : h->stream2;
+        if (c == 1) HIP_TRY(hipStreamWaitEvent(st, h->ev_ready, 0));
+        a.order = C.d_order; a.counter = C.d_counter; a.ws = C.d_ws; a.slot_bytes = C.slot_bytes; a.S = C.S;
+        a.lds_cols = C.lds_cols; a.n_genes = C.n;
+        HIP_TRY(hipEventRecord(c == 0 ? h->ev0 : h->ev2a, st));
+        const int lrc = C.ks->baseline(a, C.slots, C.dyn_lds, st);
         if (lrc != 0) return fail(DN_E_HIP, std::string("k_baseline launch: ") + hipGetErrorString((hipError_t) lrc));
+        HIP_TRY(hipEventRecord(c == 0 ? h->ev1 : h->ev2b, st));
     }
-    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    if (h->cls[1].n > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev2b, 0));     // results are copied on the main stream
     HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
     if (trace)
         HIP_TRY(hipMemcpyAsync(trace, h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (h->cls[0].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[0].last_ms, h->ev0, h->ev1));
+    if (h->cls[1].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[1].last_ms, h->ev2a, h->ev2b));
+    h->last_ms = h->cls[0].n > 0 ? h->cls[0].last_ms : h->cls[1].last_ms;
     h->have_estimate_state = prm->want_estimates != 0;
     return DN_OK;
 }
@@ -393,6 +465,9 @@ int dn_fetch_estimates(dn_handle h, double *out)
 
 double dn_last_kernel_ms(dn_handle h) { return h ? (double) h->last_ms : 0.0; }
 const char *dn_main_kernel_name(dn_handle h) { return (h && h->ks) ? h->ks->baseline_name : ""; }
+double dn_class_kernel_ms(dn_handle h, int cls) { return (h && cls >= 0 && cls < 2) ? (double) h->cls[cls].last_ms : 0.0; }
+const char *dn_class_kernel_name(dn_handle h, int cls) { return (h && cls >= 0 && cls < 2 && h->cls[cls].ks && h->cls[cls].n > 0) ? h->cls[cls].ks->baseline_name : ""; }
+int32_t dn_split_length(dn_handle h) { return h ? h->split_len : 0; }
 int dn_synchronize(dn_handle h)
 {
     if (!h) return fail(DN_E_INVALID, "null handle");

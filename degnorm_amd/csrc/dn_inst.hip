@@ -53,7 +53,8 @@ static int blocks_per_cu(int which)
     return e == hipSuccess ? nb : 0;
 }
 
-const KernelSet *DN_CAT(kernel_set_p, DN_P)()
+#define DN_CAT3(a, b, c, d) DN_CAT(DN_CAT(DN_CAT(a, b), c), d)
+const KernelSet *DN_CAT3(kernel_set_p, DN_P, _nt, DN_NT)()
 {
     static char name[64];
     snprintf(name, sizeof(name), "k_baseline<%d,%d,%d>", (int) DN_P, (int) DN_NT, (int) (DN_CR));

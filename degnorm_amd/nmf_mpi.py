@@ -153,6 +153,7 @@ class ShardedNMFOA(object):
         self.dev = dev if dev is not None else _lib.Device(dev_id)
         self.kernel_ms = []
         self.traces = []
+        self.class_ms = []
         self.downsample_offsets = None                    # optional (degnorm_iter x n_local) explicit starts
         self.n_local = 0
 
@@ -188,7 +189,7 @@ class ShardedNMFOA(object):
         self.ran_baseline_selection = np.zeros((self.n_local, self.degnorm_iter), dtype=bool)
         self._rng = np.random.RandomState(self.random_state)
         self.x_adj = None
-        self.kernel_ms, self.traces = [], []
+        self.kernel_ms, self.traces, self.class_ms = [], [], []
         return self.scale_factors
 
     def iterate(self, i, want_estimates=False):
@@ -203,6 +204,8 @@ class ShardedNMFOA(object):
             want_estimates=want_estimates, ds_start=ds)
         self.kernel_ms.append(self.dev.last_kernel_ms())
         self.traces.append(trace)
+        if hasattr(self.dev, 'class_kernel_ms'):
+            self.class_ms.append((self.dev.class_kernel_ms(0), self.dev.class_kernel_ms(1)))
         rho[rho > 0.9] = 0.9                                          # nmf.py:398-399
         rho[rho < 0.] = 0.
         self.ran_baseline_selection[:, i] = flags

@@ -101,6 +101,11 @@ int  dn_fetch_estimates(dn_handle h, double *out);
  * on the library's own stream; kernel name via dn_main_kernel_name().                               */
 double dn_last_kernel_ms(dn_handle h);
 const char *dn_main_kernel_name(dn_handle h);
+/* Genes are run in two classes: class 0 = genes longer than dn_split_length() (256-thread workgroups, one per CU),
+ * class 1 = the others (128-thread workgroups, two per CU); one kernel launch per class and outer iteration. */
+int32_t dn_split_length(dn_handle h);
+double dn_class_kernel_ms(dn_handle h, int cls);
+const char *dn_class_kernel_name(dn_handle h, int cls);
 int  dn_synchronize(dn_handle h);
 /* Stream-copy ceiling of this device (GB/s, float4 copy of `bytes` bytes, best of `reps`).          */
 double dn_measure_copy_gbps(dn_handle h, int64_t bytes, int reps);

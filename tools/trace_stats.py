@@ -15,8 +15,11 @@ dev.upload_packed(packed, lengths, cfg['p'])
 est, cov, st = dev.ratio_svd_sums()
 scale = np.ones(cfg['p'])
 for rep in range(2):
+    t0 = time.time()
     rho, flags, tr = dev.baseline_iteration(scale, nmf_iter=T)
-    print('launch ms', dev.last_kernel_ms())
+    wall = (time.time() - t0) * 1e3
+    print('launch ms', dev.last_kernel_ms(), ' class0 %.1f ms (%s)  class1 %.1f ms (%s)  split %d  iteration wall %.1f ms' % (
+        dev.class_kernel_ms(0), dev.class_kernel_name(0), dev.class_kernel_ms(1), dev.class_kernel_name(1), dev.split_length(), wall))
 calls = tr[:, 1].astype(float); cols = tr[:, 2].astype(float); steps = tr[:, 7].astype(float)
 solves = calls * (T + 1)
 print('genes', n, 'calls/gene', calls.mean(), 'sum cols/gene', cols.mean(), 'mean n per call', cols.sum() / calls.sum())
