@@ -152,3 +152,68 @@ def test_degenerate_genes_report_status_not_crash(device):
     rho, flags, trace = device.baseline_iteration(np.ones(4), nmf_iter=20)
     assert trace[0, 3] == 0 and not flags[0] and np.all(rho[0] == 0)     # no high coverage at all -> defaults
     assert trace[1, 6] == 0
+
+
+def test_full_size_properties_config2(device):
+    """
+    BASELINE configs[1] at full size (20 000 genes x 10 samples, L ~ U[200, 5000]) cannot be compared gene by gene with
+    the reference (31 h of CPU), so the whole batch is checked through size-independent properties of the algorithm
+    (one outer iteration, nmf_iter = 8 to keep the test short):
+      * determinism: two launches give bit-identical DI scores, flags and traces;
+      * gene independence: the same genes uploaded in reversed order (different queue positions, slots, neighbours and,
+        through the split length, different workgroup shapes) give the same rows to round-off and identical traces;
+      * scale equivariance: coverage of sample i times 2^k with scale factor s_i times 2^k leaves F = x / s, hence every
+        output, bit-identical (nmf.py:142-146);
+      * the first 64 genes agree with the CPU oracle.
+    """
+    c = synth.CONFIGS['c2']
+    n, p, T = c['n_genes'], c['p'], 8
+    packed, lengths, reads, _ = synth.synth_packed(c['seed'], range(n), p, c['l_min'], c['l_max'], n_threads=16)
+    scale = np.linspace(0.7, 1.4, p)
+    device.upload_packed(packed, lengths, p)
+    rho1, fl1, tr1 = device.baseline_iteration(scale, nmf_iter=T)
+    rho2, fl2, tr2 = device.baseline_iteration(scale, nmf_iter=T)
+    assert np.array_equal(rho1, rho2) and np.array_equal(fl1, fl2) and np.array_equal(tr1[:, :40], tr2[:, :40])
+    assert np.all(tr1[:, 6] == 0) and np.isfinite(rho1).all()
+    assert (tr1[:, 1] > 1).sum() > n // 2 and set(np.unique(tr1[:, 3])) >= {0, 1, 3, 4, 6}      # every exit is exercised
+
+    # scale equivariance (exact)
+    k = np.array([1, -2, 3, 0, 2, -1, 1, 0, -3, 2])
+    offs = np.concatenate([[0], np.cumsum(lengths * p)])
+    packed_s = packed.copy()
+    for g in range(0, n, 7):                                   # every 7th gene, all of its rows
+        blk = packed_s[offs[g]:offs[g + 1]].reshape(p, int(lengths[g]))
+        blk *= (2.0 ** k)[:, None].astype(np.float32)
+    sub = np.arange(0, n, 7)
+    dev2 = type(device)(0)
+    try:
+        sub_packed = np.concatenate([packed_s[offs[g]:offs[g + 1]] for g in sub])
+        dev2.upload_packed(sub_packed, lengths[sub], p)
+        rho_s, fl_s, tr_s = dev2.baseline_iteration(scale * 2.0 ** k, nmf_iter=T)
+        sub_plain = np.concatenate([packed[offs[g]:offs[g + 1]] for g in sub])
+        dev2.upload_packed(sub_plain, lengths[sub], p)
+        rho_p, fl_p, tr_p = dev2.baseline_iteration(scale, nmf_iter=T)
+        assert np.array_equal(rho_s, rho_p) and np.array_equal(fl_s, fl_p) and np.array_equal(tr_s[:, :40], tr_p[:, :40])
+        # gene independence: the subset run alone (other neighbours, other classes) == its rows in the full run
+        np.testing.assert_allclose(rho_p, rho1[sub], rtol=1e-11, atol=1e-13)
+        np.testing.assert_array_equal(tr_p[:, :7], tr1[sub, :7])
+        # reversed order
+        rev = sub[::-1]
+        dev2.upload_packed(np.concatenate([packed[offs[g]:offs[g + 1]] for g in rev]), lengths[rev], p)
+        rho_r, fl_r, tr_r = dev2.baseline_iteration(scale, nmf_iter=T)
+        np.testing.assert_allclose(rho_r[::-1], rho_p, rtol=1e-11, atol=1e-13)
+        np.testing.assert_array_equal(tr_r[::-1, :7], tr_p[:, :7])
+    finally:
+        dev2.close()
+
+
+def test_full_size_head_vs_oracle(device, oracle):
+    c = synth.CONFIGS['c2']
+    covs = _genes(c['seed'], range(64), c['p'], c['l_min'], c['l_max'])
+    scale = np.linspace(0.7, 1.4, c['p'])
+    device.upload(covs)
+    rho, flags, trace = device.baseline_iteration(scale, nmf_iter=8)
+    rho_o, flags_o, trace_o, _ = oracle.baseline_batch(covs, scale, oracle.make_params(nmf_iter=8))
+    np.testing.assert_allclose(rho, rho_o, rtol=RTOL, atol=ATOL)
+    np.testing.assert_array_equal(flags, flags_o)
+    np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
