@@ -65,6 +65,10 @@ def cpu_baseline(cfg, p, nmf_iter, iters, n_sample):
     from degnorm_amd import synth
     orc.build()
     cores = int(orc.lib().dno_max_threads())
+    try:
+        cores = max(1, min(cores, len(os.sched_getaffinity(0))))      # the threads this process may actually run on
+    except AttributeError:
+        pass
     covs = [synth.synth_gene(cfg['seed'], g, p, cfg['l_min'], cfg['l_max'])[0] for g in range(n_sample)]
     reads = np.vstack([synth.read_counts_from_coverage(c) for c in covs])
     t0 = time.time()

@@ -217,3 +217,30 @@ def test_full_size_head_vs_oracle(device, oracle):
     np.testing.assert_allclose(rho, rho_o, rtol=RTOL, atol=ATOL)
     np.testing.assert_array_equal(flags, flags_o)
     np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
+
+
+@pytest.mark.parametrize('p', [2, 3, 7, 12, 13, 20])
+def test_sample_counts_and_edge_shapes_vs_oracle(device, oracle, p):
+    """Every compiled sample count family (templated 2..12, run-time-p above) on ragged / tiny / single-gene inputs."""
+    rng = np.random.default_rng(100 + p)
+    covs = [synth.synth_gene(9, g, p, 60, 900)[0] for g in range(10)]
+    covs += [rng.poisson(30, size=(p, L)).astype(float) for L in (2, 3, 5, 51, 64, 65, 257)]     # tiny and boundary lengths
+    covs.append(np.zeros((p, 40)))                                                                # all-zero gene
+    covs.append(np.tile(np.arange(1, 301, dtype=float), (p, 1)))                                  # exactly rank 1
+    scale = np.linspace(0.9, 1.2, p)
+    for bins, T, mhc, skip in ((20, 12, 50, False), (5, 3, 2, False), (33, 1, 10, True)):
+        device.upload(covs)
+        rho, flags, trace = device.baseline_iteration(scale, nmf_iter=T, bins=bins, min_high_coverage=mhc,
+                                                      skip_baseline_selection=skip, want_estimates=True)
+        est = device.fetch_estimates()
+        prm = oracle.make_params(nmf_iter=T, bins=bins, min_high_coverage=mhc, skip_baseline_selection=skip)
+        rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, scale, prm, want_estimates=True)
+        np.testing.assert_array_equal(trace[:, [0, 1, 2, 3, 5, 6]], trace_o[:, [0, 1, 2, 3, 5, 6]])
+        np.testing.assert_array_equal(flags, flags_o)
+        np.testing.assert_allclose(rho, rho_o, rtol=1e-8, atol=1e-10)
+        for a, b in zip(est, est_o):
+            np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8)
+    # a single gene
+    device.upload(covs[:1])
+    rho1, _, tr1 = device.baseline_iteration(scale, nmf_iter=12)
+    np.testing.assert_allclose(rho1[0], oracle.baseline_batch(covs[:1], scale, oracle.make_params(nmf_iter=12))[0][0], rtol=1e-8, atol=1e-10)
