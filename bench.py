@@ -66,8 +66,14 @@ def cpu_baseline(cfg, p, nmf_iter, iters, n_sample):
     orc.build()
     cores = int(orc.lib().dno_max_threads())
     try:
-        cores = max(1, min(cores, len(os.sched_getaffinity(0))))      # the threads this process may actually run on
+        cores = max(1, min(cores, len(os.sched_getaffinity(0))))      # the CPUs this process may run on ...
     except AttributeError:
+        pass
+    try:                                                                # ... capped by the cgroup CPU quota (GPU box: 16)
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except (OSError, ValueError):
         pass
     covs = [synth.synth_gene(cfg['seed'], g, p, cfg['l_min'], cfg['l_max'])[0] for g in range(n_sample)]
     reads = np.vstack([synth.read_counts_from_coverage(c) for c in covs])
