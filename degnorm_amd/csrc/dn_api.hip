@@ -247,8 +247,15 @@ static int finish_upload(dn_handle h, const float *host_packed)
     // gene classes
     {
         const char *env = getenv("DN_SPLIT_LEN");
-        h->split_len = env ? atoi(env) : 2700;     // flat optimum 2300-3200 on config 2 (profiles/round1)
         const dn::KernelSet *narrow = (h->ks->p != 0) ? dn::kernel_set_narrow(p) : nullptr;
+        if (env) h->split_len = atoi(env);
+        else if (narrow) {
+            // narrow class = genes up to ~3.1x the columns its workgroups can keep in LDS (measured flat optimum
+            // 2300-3200 bases at p = 10, where a 128-thread workgroup holds 860 columns: profiles/round1)
+            const int per_cu_n = std::max(1, narrow->blocks_per_cu(0));
+            const int64_t lds_n = (160 * 1024) / per_cu_n - (int64_t) narrow->static_lds_bytes - 256;
+            h->split_len = (int32_t) std::max<int64_t>(0, (int64_t) (3.1 * (double) (lds_n / (8 * (int64_t) (p + (p & 1))))));
+        }
         if (!narrow) h->split_len = 0;
         std::vector<int32_t> ord[2];
         for (int32_t g : order) ord[(h->split_len > 0 && h->glen[g] <= h->split_len) ? 1 : 0].push_back(g);   // stays longest-first
