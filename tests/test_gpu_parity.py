@@ -244,3 +244,39 @@ def test_sample_counts_and_edge_shapes_vs_oracle(device, oracle, p):
     device.upload(covs[:1])
     rho1, _, tr1 = device.baseline_iteration(scale, nmf_iter=12)
     np.testing.assert_allclose(rho1[0], oracle.baseline_batch(covs[:1], scale, oracle.make_params(nmf_iter=12))[0][0], rtol=1e-8, atol=1e-10)
+
+
+def test_api_lifecycle_and_seeded_downsampling(tmp_path):
+    """Re-use of one model / device with different shapes, seeded systematic sampling, estimate shapes, result files."""
+    from collections import OrderedDict
+    import pandas as pd
+    from degnorm_amd.nmf import GeneNMFOA
+    cov6, reads6, _ = synth.synth_dataset(6, 20, 6, 300, 900)
+    cov4, reads4, _ = synth.synth_dataset(1, 12, 4, 1000, 1000)
+    m = GeneNMFOA(degnorm_iter=2, nmf_iter=10, downsample_rate=7, random_state=5)
+    est_a = m.run(cov6, reads6)
+    rho_a, scale_a = m.rho.copy(), m.scale_factors.copy()
+    est_b = m.run(cov6, reads6)                                  # same object, same seed: identical
+    assert np.array_equal(rho_a, m.rho) and np.array_equal(scale_a, m.scale_factors)
+    assert all(np.array_equal(a, b) for a, b in zip(est_a, est_b))
+    m2 = GeneNMFOA(degnorm_iter=2, nmf_iter=10, downsample_rate=7, random_state=6)
+    m2.run(cov6, reads6)
+    assert not np.array_equal(rho_a, m2.rho)                     # another seed: other sampled positions
+    for e, c in zip(est_a, cov6.values()):
+        assert e.shape == c.shape and e.dtype == np.float64 and np.isfinite(e).all()   # visualizations.py:81-82 needs equal shapes
+    # the same model on another sample count
+    m.downsample_rate = 1
+    m.min_high_coverage = 50
+    est_c = m.fit(cov4, reads4)
+    assert m.p == 4 and m.rho.shape == (12, 4) and len(est_c) == 12
+    genes_df = pd.DataFrame({'chr': ['c%d' % (k % 2) for k in range(12)], 'gene': list(cov4.keys())})
+    m.save_results(est_c, genes_df, output_dir=str(tmp_path))
+    di = pd.read_csv(tmp_path / 'degradation_index_scores.csv')
+    assert list(di.gene) == list(cov4.keys()) and list(di.columns[2:]) == ['sample_%d' % (i + 1) for i in range(4)]
+    np.testing.assert_allclose(di.iloc[:, 2:].values, m.rho)
+    # over-approximation where the reference guarantees it: estimates >= F on every gene that was re-expanded or clamped
+    tr = m.traces[-1]
+    F = [(c.T / (m.scale_factors / m.norm_factors)).T for c in cov4.values()]      # scale factors used by the last iteration
+    for k in range(12):
+        if tr[k, 3] in (5, 6):                                                       # fallback exits clamp to F (nmf.py:345, :352)
+            assert (est_c[k] >= F[k] * (1 - 1e-12)).all()
