@@ -55,6 +55,7 @@ def load(build_if_missing=False):
     lib.dn_ratio_svd_sums.argtypes = [vp, P(dbl), P(dbl), P(i32)]
     lib.dn_baseline_iteration.argtypes = [vp, P(dbl), P(Params), P(i64), P(dbl), P(i32), P(i32)]
     lib.dn_fetch_estimates.argtypes = [vp, P(dbl)]
+    lib.dn_fetch_estimates_subset.argtypes = [vp, i64, P(i64), P(dbl)]
     lib.dn_last_kernel_ms.argtypes = [vp]
     lib.dn_last_kernel_ms.restype = dbl
     lib.dn_main_kernel_name.argtypes = [vp]
@@ -179,6 +180,23 @@ class Device:
                                               _p(rho, ctypes.c_double), _p(flags, ctypes.c_int32),
                                               _p(trace, ctypes.c_int32) if want_trace else None))
         return rho, flags.astype(bool), trace
+
+    def fetch_estimates_subset(self, gene_ids):
+        """Estimates of the chosen genes only (indices in upload order): list of (p x L_g) float64 arrays."""
+        ids = np.ascontiguousarray(gene_ids, dtype=np.int64)
+        if ids.ndim != 1 or ids.size == 0:
+            raise ValueError('gene_ids must be a non-empty 1-d sequence')
+        if ids.min() < 0 or ids.max() >= self.n:
+            raise ValueError('gene id out of range')
+        uniq, inverse = np.unique(ids, return_inverse=True)             # the C ABI takes each gene once
+        flat = np.empty(int(self.lengths[uniq].sum()) * self.p, dtype=np.float64)
+        _check(self.lib.dn_fetch_estimates_subset(self.h, uniq.size, _p(uniq, ctypes.c_int64), _p(flat, ctypes.c_double)))
+        mats, o = [], 0
+        for L in self.lengths[uniq]:
+            cnt = self.p * int(L)
+            mats.append(flat[o:o + cnt].reshape(self.p, int(L)))
+            o += cnt
+        return [mats[k] for k in inverse]
 
     def fetch_estimates(self):
         """List of (p x L_g) float64 arrays, views into one flat buffer, in upload order."""

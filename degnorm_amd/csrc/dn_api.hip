@@ -470,6 +470,45 @@ int dn_fetch_estimates(dn_handle h, double *out)
     return DN_OK;
 }
 
+int dn_fetch_estimates_subset(dn_handle h, int64_t n_sel, const int64_t *gene_ids, double *out)
+{
+    if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_fetch_estimates_subset: nothing uploaded");
+    if (!h->have_estimate_state) return fail(DN_E_STATE, "dn_fetch_estimates_subset: last iteration did not run with want_estimates = 1");
+    if (n_sel <= 0 || !gene_ids || !out) return fail(DN_E_INVALID, "dn_fetch_estimates_subset: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<int64_t> ooff(h->n, -1);
+    std::vector<int32_t> tg, tc;
+    int64_t total = 0;
+    for (int64_t k = 0; k < n_sel; k++) {
+        const int64_t g = gene_ids[k];
+        if (g < 0 || g >= h->n) return fail(DN_E_INVALID, "dn_fetch_estimates_subset: gene id out of range");
+        if (ooff[g] >= 0) return fail(DN_E_INVALID, "dn_fetch_estimates_subset: duplicate gene id");
+        ooff[g] = total;
+        total += (int64_t) h->p * h->glen[g];
+        for (int32_t c = 0; c < h->glen[g]; c += 256) { tg.push_back((int32_t) g); tc.push_back(c); }
+    }
+    double *d_out = nullptr; int64_t *d_ooff = nullptr; int32_t *d_tg = nullptr, *d_tc = nullptr;
+    HIP_TRY(hipMalloc(&d_out, sizeof(double) * (size_t) total));
+    HIP_TRY(hipMalloc(&d_ooff, sizeof(int64_t) * (size_t) h->n));
+    HIP_TRY(hipMalloc(&d_tg, sizeof(int32_t) * tg.size()));
+    HIP_TRY(hipMalloc(&d_tc, sizeof(int32_t) * tc.size()));
+    HIP_TRY(hipMemcpyAsync(d_ooff, ooff.data(), sizeof(int64_t) * (size_t) h->n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_tg, tg.data(), sizeof(int32_t) * tg.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_tc, tc.data(), sizeof(int32_t) * tc.size(), hipMemcpyHostToDevice, h->stream));
+    dn::EstArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.kfin = h->d_kfin; a.emode = h->d_emode;
+    a.svec = h->d_svec; a.svoff = h->d_svoff; a.out = d_out; a.ooff = d_ooff; a.n_genes = (int32_t) h->n; a.p = h->p;
+    for (int i = 0; i < dn::P_MAX; i++) a.scale[i] = i < h->p ? h->last_scale[i] : 1.0;
+    h->ks->est(a, d_tg, d_tc, (int) tg.size(), h->stream);
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t) total, hipMemcpyDeviceToHost, h->stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(h->stream);
+    (void) hipFree(d_out); (void) hipFree(d_ooff); (void) hipFree(d_tg); (void) hipFree(d_tc);
+    if (le != hipSuccess) return fail(DN_E_HIP, std::string("dn_fetch_estimates_subset: ") + hipGetErrorString(le));
+    return DN_OK;
+}
+
 double dn_last_kernel_ms(dn_handle h) { return h ? (double) h->last_ms : 0.0; }
 const char *dn_main_kernel_name(dn_handle h) { return (h && h->ks) ? h->ks->baseline_name : ""; }
 double dn_class_kernel_ms(dn_handle h, int cls) { return (h && cls >= 0 && cls < 2) ? (double) h->cls[cls].last_ms : 0.0; }

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_estimates_gen(EstArgs A, const int32_t 
     const int L = A.glen[g], p = A.p;
     if (j >= L) return;
     const float *x = A.cov + A.goff[g];
-    double *o = A.out + A.goff[g];
+    double *o = A.out + (A.ooff ? A.ooff[g] : A.goff[g]);
     const int em = A.emode[g];
     const double *K = A.kfin + (size_t) g * p;
     if (em == EM_INPUT) {

@@ -105,7 +105,8 @@ struct EstArgs {
     const int32_t *emode;
     const double  *svec;
     const int64_t *svoff;
-    double        *out;        // same offsets as cov (goff), float64
+    double        *out;        // float64; gene g at ooff[g] (or at goff[g], the coverage offsets, when ooff is null)
+    const int64_t *ooff;
     int32_t        n_genes;
     int32_t        p;
     double         scale[P_MAX];
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(256) void k_estimates(EstArgs A, const int32_t *__r
     const int L = A.glen[g];
     if (j >= L) return;
     const float *x = A.cov + A.goff[g];
-    double *o = A.out + A.goff[g];
+    double *o = A.out + (A.ooff ? A.ooff[g] : A.goff[g]);
     const int em = A.emode[g];
     double f[P], K[P];
 #pragma unroll

@@ -178,6 +178,17 @@ class GeneNMFOA(object):
 
     fit = run   # BASELINE.json names the entry point `fit`; the reference's is `run`
 
+    def estimates_for(self, genes):
+        """
+        Estimated coverage matrices of a few genes only (by name), rebuilt on demand from the device-side state of the
+        last iteration -- what the plot / report steps need (`__main__.py:291-316`, `report.py:97-113`) without
+        materialising all n estimates.
+        """
+        if not self.fitted or self._dev is None:
+            raise ValueError('Model not yet fit. NMF-OA has not been run.')
+        pos = {g: k for k, g in enumerate(self.genes)}
+        return self._dev.fetch_estimates_subset([pos[g] for g in genes])
+
     # ------------------------------------------------------------------------------------------- #
     def save_results(self, estimates, gene_manifest_df, output_dir='.', sample_ids=None):
         """

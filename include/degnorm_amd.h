@@ -95,6 +95,9 @@ int  dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *pr
  * Replaces: the `estimate` output of baseline_selection (nmf.py:355-369), returned by run() (nmf.py:601).
  * out: float64, gene g at element offset p * sum(lengths[:g]), p x L_g row-major.                     */
 int  dn_fetch_estimates(dn_handle h, double *out);
+/* The same for a chosen subset (plots and reports only read a handful of genes, report.py:97-113,
+ * __main__.py:291-316): gene_ids[n_sel] in upload order; out holds the selected genes back to back, in that order. */
+int  dn_fetch_estimates_subset(dn_handle h, int64_t n_sel, const int64_t *gene_ids, double *out);
 
 /* Measurement hooks (bench.py) -------------------------------------------------------------------- */
 /* Device time in ms of the most recent dn_baseline_iteration's main kernel, measured with HIP events

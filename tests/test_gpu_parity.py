@@ -280,3 +280,14 @@ def test_api_lifecycle_and_seeded_downsampling(tmp_path):
     for k in range(12):
         if tr[k, 3] in (5, 6):                                                       # fallback exits clamp to F (nmf.py:345, :352)
             assert (est_c[k] >= F[k] * (1 - 1e-12)).all()
+
+
+def test_estimates_on_demand_match_full_fetch():
+    """estimates of a few genes rebuilt on demand equal the rows of the full fetch."""
+    G, m, est = _run_fixture('run_c1')
+    pick = [m.genes[k] for k in (7, 0, 55, 99, 7)]
+    sub = m.estimates_for(pick)
+    for name, e in zip(pick, sub):
+        np.testing.assert_array_equal(e, est[m.genes.index(name)])
+    with pytest.raises(ValueError):
+        m._dev.fetch_estimates_subset([10 ** 6])
