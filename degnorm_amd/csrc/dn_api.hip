@@ -274,6 +274,15 @@ static int finish_upload(dn_handle h, const float *host_packed)
             C.S = (h->glen[ord[c][0]] + 63) & ~63;                    // longest gene of the class
             // slot: Fs, Fb (fp32 [p][S]) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
             C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double));
+            {
+                // one very long gene sizes every slot of its class: keep the scratch within a share of free HBM by
+                // running fewer persistent workgroups rather than failing
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                const int64_t budget = (int64_t) (free_b / 3);
+                if (C.slot_bytes > budget) return fail(DN_E_INVALID, "a gene is too long for the device scratch (" + std::to_string(C.S) + " columns)");
+                C.slots = (int) std::max<int64_t>(1, std::min<int64_t>(C.slots, budget / C.slot_bytes));
+            }
             HIP_TRY(hipMalloc(&C.d_ws, (size_t) C.slot_bytes * (size_t) std::max(C.slots, 1)));
             // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
             const int64_t lds_per_block = (160 * 1024) / per_cu - (int64_t) C.ks->static_lds_bytes - 256;

@@ -291,3 +291,20 @@ def test_estimates_on_demand_match_full_fetch():
         np.testing.assert_array_equal(e, est[m.genes.index(name)])
     with pytest.raises(ValueError):
         m._dev.fetch_estimates_subset([10 ** 6])
+
+
+def test_one_very_long_gene_vs_oracle(device, oracle):
+    """A 150 kb transcript next to ordinary genes (slots are sized by the longest gene of a class)."""
+    rng = np.random.default_rng(77)
+    L = 150000
+    env = 30 + 40 * np.abs(np.sin(np.linspace(0, 9, L)))
+    long_gene = rng.poisson(np.outer(rng.lognormal(0, 0.4, 4), env)).astype(float)
+    covs = [long_gene] + [synth.synth_gene(1, g, 4, 1000, 1000)[0] for g in range(6)]
+    device.upload(covs)
+    rho, flags, trace = device.baseline_iteration(np.array([0.9, 1.0, 1.1, 1.05]), nmf_iter=6, want_estimates=True)
+    rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, np.array([0.9, 1.0, 1.1, 1.05]),
+                                                           oracle.make_params(nmf_iter=6), want_estimates=True)
+    np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
+    np.testing.assert_allclose(rho, rho_o, rtol=1e-8, atol=1e-10)
+    est = device.fetch_estimates_subset([0])
+    np.testing.assert_allclose(est[0], est_o[0], rtol=1e-8, atol=1e-8)
