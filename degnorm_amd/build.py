@@ -64,6 +64,11 @@ def build_library(force=False, verbose=False):
     objs.append(o_gen)
     if force or _newer(o_gen, [gen] + hdr):
         jobs.append([hipcc] + FLAGS + ['-c', gen, '-o', o_gen])
+    asm = os.path.join(CSRC, 'dn_assemble.hip')
+    o_asm = os.path.join(OBJ, 'dn_assemble.o')
+    objs.append(o_asm)
+    if force or _newer(o_asm, [asm] + hdr):
+        jobs.append([hipcc] + FLAGS + ['-c', asm, '-o', o_asm])
     api = os.path.join(CSRC, 'dn_api.hip')
     o_api = os.path.join(OBJ, 'dn_api.o')
     objs.append(o_api)

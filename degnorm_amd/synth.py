@@ -191,3 +191,45 @@ def write_warm_start_dir(path, seed=5, n_genes=60, p=6, l_min=200, l_max=1500, c
         with open(os.path.join(path, c, 'coverage_matrices_{0}.pkl'.format(c)), 'wb') as f:
             pickle.dump(dict(per_chrom[c]), f)
     return sample_ids
+
+
+def write_chrom_coverage_dir(path, seed=8, n_samples=4, chrom='chr7', chrom_len=60000, n_genes=25, missing=(2,)):
+    """
+    Synthetic input of the coverage-merge step in the reference's layout (reads.py:785-786,
+    reads_coverage_merge.py:185-190): <path>/<sample>/chrom_coverage_<sample>_<chr>.npz holding a 1 x chrom_len CSR row
+    of integer coverage, and an exon table (chr, gene, gene_start, gene_end, start, end; 1-based inclusive) with
+    multi-exon genes, overlapping exons and ties in gene_end.  Samples listed in `missing` get no file (imputed zeros).
+    Returns (sample_ids, exon DataFrame).
+    """
+    import os
+    import pandas as pd
+    from scipy import sparse
+    rng = np.random.default_rng([int(seed), 4242])
+    sample_ids = ['smp{0}'.format(i) for i in range(n_samples)]
+    rows = []
+    pos = 500
+    for g in range(n_genes):
+        n_ex = int(rng.integers(1, 5))
+        gstart = pos
+        exons = []
+        for _ in range(n_ex):
+            ln = int(rng.integers(40, 600))
+            exons.append((pos, pos + ln - 1))
+            pos += ln + int(rng.integers(-60, 400))           # negative gap: overlapping exons
+            pos = max(pos, gstart + 1)
+        gend = max(e for _, e in exons)
+        for (a, b) in exons:
+            rows.append(dict(chr=chrom, gene='G{0:03d}'.format(g), gene_start=gstart, gene_end=gend, start=a, end=b))
+        pos = gend + int(rng.integers(50, 900))
+        if pos > chrom_len - 3000:
+            break
+    exon_df = pd.DataFrame(rows).sample(frac=1.0, random_state=int(rng.integers(1 << 30))).reset_index(drop=True)
+    os.makedirs(path, exist_ok=True)
+    for i, s in enumerate(sample_ids):
+        if i in missing:
+            continue
+        dense = rng.poisson(6.0 * (1 + i), size=chrom_len) * (rng.random(chrom_len) < 0.6)
+        os.makedirs(os.path.join(path, s), exist_ok=True)
+        sparse.save_npz(os.path.join(path, s, 'chrom_coverage_{0}_{1}.npz'.format(s, chrom)),
+                        sparse.csr_matrix(dense.astype(int).reshape(1, -1)))
+    return sample_ids, exon_df

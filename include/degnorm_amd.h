@@ -99,6 +99,21 @@ int  dn_fetch_estimates(dn_handle h, double *out);
  * __main__.py:291-316): gene_ids[n_sel] in upload order; out holds the selected genes back to back, in that order. */
 int  dn_fetch_estimates_subset(dn_handle h, int64_t n_sel, const int64_t *gene_ids, double *out);
 
+/* Coverage-matrix assembly -------------------------------------------------------------
+ * Replaces: the densify-and-slice loop of merge_chrom_coverage (reads_coverage_merge.py:283-353).
+ * Per sample i the chromosome coverage is the CSR row written by reads.py:785-786: nnz[i] positions indices[i][]
+ * (0-based) with values[i][] (nnz[i] = 0: file missing, imputed as zeros, :309-316).  Each gene's union of exons is
+ * given as chunks (<= any length): chunk c copies chunk_len[c] positions starting at chromosome position chunk_src[c]
+ * to column chunk_dst_in_gene[c] of gene chunk_gene[c].  out_packed: float32, gene g at p * sum(lengths[:g]),
+ * p rows of lengths[g] -- the layout dn_upload_packed takes.  device_ms (nullable): device time of the assembly. */
+int  dn_assemble_coverage(int device, int64_t chrom_len, int32_t p, const int64_t *nnz,
+                          const int32_t *const *indices, const float *const *values,
+                          int64_t n_genes, const int64_t *lengths,
+                          int64_t n_chunks, const int32_t *chunk_gene, const int64_t *chunk_src,
+                          const int64_t *chunk_dst_in_gene, const int32_t *chunk_len,
+                          float *out_packed, double *device_ms);
+const char *dn_assemble_last_error(void);
+
 /* Measurement hooks (bench.py) -------------------------------------------------------------------- */
 /* Device time in ms of the most recent dn_baseline_iteration's main kernel, measured with HIP events
  * on the library's own stream; kernel name via dn_main_kernel_name().                               */

@@ -16,6 +16,8 @@ Sections:
     run_c2     G4     GeneNMFOA.run on a 64-gene draw of config 2 (p=10, L~U[200,5000]), 3 iterations
     mpi        G5     run_gene_nmfoa_mpi through an in-process fake communicator (2 and 3 ranks)
     dsamp      G6     downsampled runs (rate 50) with captured systematic-sample offsets
+    warm       G7     warm-start directory -> filter -> run -> save_results CSVs
+    merge      f-3    merge_chrom_coverage on per-sample chromosome CSR vectors
 """
 import os
 import sys
@@ -325,8 +327,28 @@ def sec_warm():
     print('warm done:', len(loaded_order), 'loaded,', di.shape[0], 'run')
 
 
+def sec_merge():
+    """
+    SURVEY 8(f-3): the reference's merge_chrom_coverage (reads_coverage_merge.py:167-372) on a synthetic directory of
+    per-sample chromosome CSR vectors.  numpy >= 2 removed the `np.float_` alias the reference uses at :353; it is
+    restored here (an alias of float64, nothing else changes) so that the reference function runs unmodified.
+    """
+    import tempfile
+    if not hasattr(np, 'float_'):
+        np.float_ = np.float64
+    from degnorm.reads_coverage_merge import merge_chrom_coverage
+    d = tempfile.mkdtemp(prefix='dn_merge_')
+    sample_ids, exon_df = synth.write_chrom_coverage_dir(d)
+    out = merge_chrom_coverage(d, sample_ids, exon_df, verbose=False)
+    genes = list(out.keys())
+    np.savez_compressed(os.path.join(HERE, 'merge.npz'), genes=np.array(genes), sample_ids=np.array(sample_ids),
+                        lengths=np.array([out[g].shape[1] for g in genes]),
+                        flat=np.concatenate([out[g].reshape(-1) for g in genes]))
+    print('merge done:', len(genes), 'genes', sum(out[g].size for g in genes), 'values')
+
+
 SECTIONS = OrderedDict(kat=sec_kat, genes=sec_genes, run_c1=sec_run_c1, run_c2=sec_run_c2, mpi=sec_mpi,
-                       dsamp=sec_dsamp, warm=sec_warm)
+                       dsamp=sec_dsamp, warm=sec_warm, merge=sec_merge)
 
 if __name__ == '__main__':
     import logging
