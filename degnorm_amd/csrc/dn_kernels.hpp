@@ -115,16 +115,11 @@ struct EstArgs {
 // ---------------------------------------------------------------------------------------------------
 // LDS layout of one workgroup (static part; the lambda tile is dynamic shared memory behind it).
 // ---------------------------------------------------------------------------------------------------
-constexpr int RED_ROWS = 8;                  // entries reduced per round
-constexpr int RED_LD = 66;                   // row stride in doubles: 528 B, 16-B aligned, bank-skewed by 4 dwords
-constexpr int WAVE_RED_DOUBLES = RED_ROWS * RED_LD;
-
 template <int P, int NT>
 struct Smem {
     static constexpr int W = NT / 64;
     static constexpr int NG = P * (P + 1) / 2;
     static constexpr int NX = NG > 64 ? NG : 64;
-    double red[W][WAVE_RED_DOUBLES];         // per-wave transposed-reduce tile (wave-private)
     double xw[W][NX];                        // per-wave totals (cross-wave combine)
     double tot[NX];                          // block totals (broadcast)
     double ss[MAX_BINS];                     // per-bin mean squared residual
@@ -178,37 +173,48 @@ __device__ __forceinline__ double sum8(double s)
     return s;
 }
 
+// Register-only reduce-scatter steps (gfx950 v_permlane32_swap / v_permlane16_swap): two values enter, one leaves.
+//   swap32_add(a, b): lanes 0-31 hold a[l] + a[l+32], lanes 32-63 hold b[l-32] + b[l]
+//   swap16_add(a, b): rows (16 lanes) 0..3 hold a.row0 + a.row1, b.row0 + b.row1, a.row2 + a.row3, b.row2 + b.row3
+typedef unsigned dn_uint2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double swap32_add(double a, double b)
+{
+    const dn_uint2 lo = __builtin_amdgcn_permlane32_swap((unsigned) __double2loint(a), (unsigned) __double2loint(b), false, false);
+    const dn_uint2 hi = __builtin_amdgcn_permlane32_swap((unsigned) __double2hiint(a), (unsigned) __double2hiint(b), false, false);
+    return __hiloint2double((int) hi.x, (int) lo.x) + __hiloint2double((int) hi.y, (int) lo.y);
+}
+__device__ __forceinline__ double swap16_add(double a, double b)
+{
+    const dn_uint2 lo = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(a), (unsigned) __double2loint(b), false, false);
+    const dn_uint2 hi = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(a), (unsigned) __double2hiint(b), false, false);
+    return __hiloint2double((int) hi.x, (int) lo.x) + __hiloint2double((int) hi.y, (int) lo.y);
+}
+
 // Block-wide sum of N register values; the totals are left in sm.tot[0..N), bit-identical for every reader
 // (the wave-uniform branches of the state machine rely on that).
-// Per wave: transposed tree through a private LDS tile -- lane l writes 8 of its partials as column l of an
-// [entry][lane] tile, lane (e, seg) adds 8 lanes of entry e in a fixed order, three DPP steps finish the 64
-// lanes: ~4 LDS/ALU ops per value where a butterfly needs 18.  Then one cross-wave add through LDS.
+// Per wave, in registers only: a reduce-scatter over the four 16-lane rows (pairs of entries through
+// v_permlane32_swap, pairs of those through v_permlane16_swap: N values -> N/4 registers whose row r holds entry
+// 4k + {0,2,1,3}[r] summed over lanes {l, l+16, l+32, l+48}), then a 4-step DPP all-reduce inside each row.
+// ~5.4 VALU ops per value and no LDS traffic; the summation order is fixed.  Then one cross-wave add through LDS.
 template <int N, int P, int NT, typename VT>
 __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm)
 {
     static_assert(N <= Smem<P, NT>::NX, "xw too small");
     constexpr int W = NT / 64;
-    constexpr int ROUNDS = (N + RED_ROWS - 1) / RED_ROWS;
+    constexpr int R1 = (N + 1) / 2, R2 = (R1 + 1) / 2;
     const int lane = lane_id(), w = wave_id();
-    const int e = lane >> 3, seg = lane & 7;
     double *dst = (W > 1) ? sm.xw[w] : sm.tot;
-    double *tile = sm.red[w];
+    double h[R1];
 #pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
+    for (int j = 0; j < R1; j++) h[j] = swap32_add((double) g[2 * j], 2 * j + 1 < N ? (double) g[2 * j + 1] : 0.0);
+    const int row = lane >> 4;
+    const int sub = ((row & 1) << 1) | (row >> 1);
 #pragma unroll
-        for (int q = 0; q < RED_ROWS; q++) {
-            if (r * RED_ROWS + q < N) tile[q * RED_LD + lane] = (double) g[r * RED_ROWS + q];
-        }
-        wave_fence();
-        double s = 0.0;
-        {
-            const double2 *row = reinterpret_cast<const double2 *>(tile + e * RED_LD + seg * 8);
-#pragma unroll
-            for (int c = 0; c < 4; c++) { const double2 v = row[c]; s += v.x; s += v.y; }
-        }
+    for (int k = 0; k < R2; k++) {
+        double s = swap16_add(h[2 * k], 2 * k + 1 < R1 ? h[2 * k + 1] : 0.0);
         s = sum8(s);
-        if (seg == 0 && r * RED_ROWS + e < N) dst[r * RED_ROWS + e] = s;
-        wave_fence();
+        s += dpp_mov<0x140>(s);     // row_mirror: lane i <-> 15 - i
+        if ((lane & 15) == 0 && 4 * k + sub < N) dst[4 * k + sub] = s;
     }
     if constexpr (W > 1) {
         __syncthreads();
