@@ -18,7 +18,13 @@
 #define DN_FOR_EACH_P(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 
 namespace dn {
-#define DN_DECL(P) const KernelSet *kernel_set_p##P##_nt256(); const KernelSet *kernel_set_p##P##_nt128();
+#ifndef DN_WIDE_NT
+#define DN_WIDE_NT 256               // threads per workgroup of the wide gene class (build.py compiles this variant)
+#endif
+#define DN_CAT4_(a, b, c, d) a##b##c##d
+#define DN_CAT4(a, b, c, d) DN_CAT4_(a, b, c, d)
+#define DN_WIDE_SET(P) DN_CAT4(kernel_set_p, P, _nt, DN_WIDE_NT)
+#define DN_DECL(P) const KernelSet *DN_WIDE_SET(P)(); const KernelSet *kernel_set_p##P##_nt128();
 DN_FOR_EACH_P(DN_DECL)
 #undef DN_DECL
 
@@ -40,7 +46,7 @@ const KernelSet *kernel_set_for(int p)
     const char *force = getenv("DN_FORCE_GENERIC");
     if (force && force[0] == '1' && p >= 2 && p <= P_MAX) return kernel_set_generic();
     switch (p) {
-#define DN_CASE(P) case P: return kernel_set_p##P##_nt256();
+#define DN_CASE(P) case P: return DN_WIDE_SET(P)();
         DN_FOR_EACH_P(DN_CASE)
 #undef DN_CASE
         default: return (p > 12 && p <= P_MAX) ? kernel_set_generic() : nullptr;

@@ -427,6 +427,174 @@ __device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], d
     return steps + 1;
 }
 
+// The same eigenpair through the fp64 matrix cores: repeated squaring instead of single power steps.
+// v_mfma_f64_16x16x4_f64 (gfx950, 64 cycles) takes A as lane (i = l & 15, k = l >> 4) -> A[i][k], B as lane
+// (j, k) -> B[k][j] and returns D[q + 4 r][j] in register r of lane (j, q = l >> 4).  For a symmetric matrix
+// held as h[kb] = H[l & 15][(l >> 4) + 4 kb] the product H H = sum_kb mfma(h[kb], h[kb]) therefore comes back in
+// the layout it went in, so M squarings cost M * ceil(p / 4) MFMAs and no data movement, and one step with
+// H = ((G - mu I) / tr)^(2^M) equals 2^M shifted power steps.  The iterate lives in the B layout (register kb of
+// lane group q holds v[q + 4 kb], every column alike), which is also what the step returns; norms are all-reduced
+// over the four 16-lane rows with the permlane swaps, so every lane sees identical bits.  The shift uses the
+// eigenvalue of the previous solve (theta on entry, 0 on a cold start).  theta = u^T G u of the unshifted matrix.
+typedef double dn_double4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double allsum_rows(double v)
+{
+    v = swap32_add(v, v);
+    return swap16_add(v, v);
+}
+
+#ifndef DN_EIG_SQUARINGS
+#define DN_EIG_SQUARINGS 2
+#endif
+
+__device__ __forceinline__ double rsqrt_newton(double n2)
+{
+    // 1/sqrt(n2): hardware estimate + two Newton steps
+    double inv = __builtin_amdgcn_rsq(n2);
+    inv = inv * fma(-0.5 * n2 * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * n2 * inv, inv, 1.5);
+    return inv;
+}
+
+template <int KB>
+__device__ __forceinline__ dn_double4 mfma_sym(const double (&h)[KB], const double (&v)[KB])
+{
+    dn_double4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) y = __builtin_amdgcn_mfma_f64_16x16x4f64(h[kb], v[kb], y, 0, 0, 0);
+    return y;
+}
+
+template <int P>
+__device__ __forceinline__ int top_eig_mfma(const double *tot, double (&u)[P], double &theta, bool exact_theta)
+{
+    static_assert(P <= 16, "one 16 x 16 MFMA tile");
+    constexpr int KB = (P + 3) / 4;
+    constexpr int M = DN_EIG_SQUARINGS;
+    const int c = lane_id() & 15, q = lane_id() >> 4;
+    double g[KB], h[KB], v[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        const int k = q + 4 * kb;
+        const bool valid = c < P && k < P;
+        const int a = c > k ? c : k, b = c > k ? k : c;
+        const double t = tot[valid ? a * (a + 1) / 2 + b : 0];
+        g[kb] = valid ? t : 0.0;
+    }
+    double dg[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) dg[i] = tot[i * (i + 1) / 2 + i];
+#pragma unroll
+    for (int w = 1; w < P; w *= 2) {                                   // pairwise tree: short dependency chain
+#pragma unroll
+        for (int i = 0; i + w < P; i += 2 * w) dg[i] += dg[i + w];
+    }
+    const double tr = dg[0];
+    if (!(tr > 0.0)) { theta = 0.0; return 1; }
+    const double sc = __builtin_amdgcn_rcp(tr);                        // only a scale: the estimate is good enough
+    double mu = (tr - theta) * (1.0 / (double) (P > 1 ? P - 1 : 1));
+    mu = (theta > 0.0 && mu > 0.0 && mu < 0.5 * theta) ? mu * sc : 0.0;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        g[kb] *= sc;
+        h[kb] = (c == q + 4 * kb && c < P) ? g[kb] - mu : g[kb];      // rows / columns >= P are zero and stay zero
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const dn_double4 d = mfma_sym<KB>(h, h);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) h[kb] = d[kb];
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        double w = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++)
+            if (qq + 4 * kb < P) w = (q == qq) ? u[qq + 4 * kb] : w;
+        v[kb] = w;
+    }
+    // two steps back to back; the norm of the first iterate is formed in the shadow of the second product
+    const dn_double4 y1 = mfma_sym<KB>(h, v);
+    double y1r[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) y1r[kb] = y1[kb];
+    const dn_double4 y2 = mfma_sym<KB>(h, y1r);
+    double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) { p1 = fma(y1[kb], y1[kb], p1); p2 = fma(y2[kb], y2[kb], p2); }
+    const double n1 = allsum_rows(p1), n2 = allsum_rows(p2);
+    if (!(n1 > 0.0) || !(n2 > 0.0)) { theta = 0.0; return 1; }
+    const double i1 = rsqrt_newton(n1), i2 = rsqrt_newton(n2);
+    double e1p = 0.0, e2p = 0.0;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        const double u1 = y1[kb] * i1, u2 = y2[kb] * i2;
+        const double da = u1 - v[kb], db = u2 - u1;
+        e1p = fma(da, da, e1p); e2p = fma(db, db, e2p);
+        v[kb] = u2;
+    }
+    double d2_prev = allsum_rows(e1p), d2 = allsum_rows(e2p);
+    double n_last = n2 * i2, i_prev = i1;                               // |y2| and 1 / |y1|: y2 = H y1
+    int steps = 1 + (2 << M);
+    // as in top_eig_rows: stop when the error predicted from the contraction between two checks is ~1e-13
+    // (ratio = d2 / d2_prev < 0.25 and 4 d2 ratio <= 1e-26, written without the division)
+    while (!(d2 <= 1e-26 || (4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev)) && steps < 4000) {
+        const dn_double4 y = mfma_sym<KB>(h, v);
+        double part = 0.0;
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) part = fma(y[kb], y[kb], part);
+        const double nn = allsum_rows(part);
+        if (!(nn > 0.0)) { theta = 0.0; return steps; }
+        const double inv = rsqrt_newton(nn);
+        n_last = nn * inv; i_prev = 1.0;                               // v was a unit vector here
+        double dpart = 0.0;
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) {
+            const double un = y[kb] * inv;
+            const double d = un - v[kb];
+            dpart = fma(d, d, dpart);
+            v[kb] = un;
+        }
+        d2_prev = d2;
+        d2 = allsum_rows(dpart);
+        steps += 1 << M;
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const double t = v[i >> 2];
+        u[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), 16 * (i & 3)),
+                                __builtin_amdgcn_readlane(__double2loint(t), 16 * (i & 3)));
+    }
+    if (exact_theta) {
+        const dn_double4 w = mfma_sym<KB>(g, v);                       // Rayleigh quotient of the unshifted matrix
+        double tp = 0.0;
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) tp = fma(v[kb], w[kb], tp);
+        theta = allsum_rows(tp) * tr;
+    } else {
+        // only the next solve's shift reads it: dominant eigenvalue of H ~ |H y| / |y|, and H = ((G - mu I) / tr)^(2^M)
+        double lam = n_last * i_prev;
+#pragma unroll
+        for (int m = 0; m < M; m++) lam = __builtin_amdgcn_sqrt(lam);
+        theta = (lam + mu) * tr;
+    }
+    return steps + 1;
+}
+
+#ifndef DN_EIG_MFMA
+#define DN_EIG_MFMA 1
+#endif
+template <int P>
+__device__ __forceinline__ int top_eig_wave(const double *tot, double (&u)[P], double &theta, bool exact_theta)
+{
+#if DN_EIG_MFMA
+    return top_eig_mfma<P>(tot, u, theta, exact_theta);
+#else
+    return top_eig_rows<P>(tot, u, theta);
+#endif
+}
+
 typedef DN_GRAM_T gram_t;      // per-lane Gram accumulators: double (exact mode) or float (mixed mode)
 
 template <int P, typename T>
@@ -647,9 +815,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     const double u0 = 1.0 / sqrt((double) P);
 #pragma unroll
     for (int i = 0; i < P; i++) u[i] = u0;
-    steps += top_eig_rows<P>(sm.tot, u, theta);
-#pragma unroll
-    for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
+    steps += top_eig_wave<P>(sm.tot, u, theta, T == 0);              // u comes back in scalar registers
 
 #pragma unroll
     for (int cc = 0; cc < CR; cc++) {                                  // lmbda = zeros (nmf.py:90): a = x
@@ -733,9 +899,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         DN_T1(0); }
         { DN_T0(); block_sum_lds<NG, P, NT, gram_t>(G, sm); DN_T1(1); }
         { DN_T0();
-        steps += top_eig_rows<P>(sm.tot, u, theta);
-#pragma unroll
-        for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
+        steps += top_eig_wave<P>(sm.tot, u, theta, t == T - 1);      // sigma^2 is only read after the last solve
         DN_T1(2); }
     }
 
