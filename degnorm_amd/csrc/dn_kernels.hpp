@@ -743,18 +743,38 @@ __device__ __forceinline__ void lds_col_write(double *col, const double (&a)[PS]
     for (int i = 0; i < PS; i += 2) *reinterpret_cast<double2 *>(col + i) = make_double2(a[i], a[i + 1]);
 }
 
+// Column k of the compacted counts is P contiguous floats (Fb[k * P + i]): three vector loads at p = 10 instead of
+// ten scalar ones; a wave reads 64 * 4P contiguous bytes.  Columns are only 4-byte aligned, which global loads allow.
+typedef float dn_f4 __attribute__((ext_vector_type(4)));
+typedef float dn_f2 __attribute__((ext_vector_type(2)));
+typedef dn_f4 dn_f4u __attribute__((aligned(4)));
+typedef dn_f2 dn_f2u __attribute__((aligned(4)));
+typedef const dn_f4u __attribute__((address_space(1))) *gF4_cptr;
+typedef const dn_f2u __attribute__((address_space(1))) *gF2_cptr;
+
 template <int P>
-__device__ __forceinline__ void load_x(gF_cptr Fb, int S, int k, float (&x)[P])
+__device__ __forceinline__ void load_x(gF_cptr Fb, int k, float (&x)[P])
 {
+    gF_cptr col = Fb + (size_t) k * P;
 #pragma unroll
-    for (int i = 0; i < P; i++) x[i] = Fb[(size_t) i * S + k];
+    for (int i = 0; i + 4 <= P; i += 4) {
+        const dn_f4 v = *(gF4_cptr) (col + i);
+        x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
+    }
+    if constexpr ((P & 3) >= 2) {
+        const dn_f2 v = *(gF2_cptr) (col + (P & ~3));
+        x[P & ~3] = v.x; x[(P & ~3) + 1] = v.y;
+    }
+    if constexpr (P & 1) x[P - 1] = col[P - 1];
 }
 
 template <int P>
-__device__ __forceinline__ void load_f(gF_cptr Fb, int S, int k, const double (&inv)[P], double (&f)[P])
+__device__ __forceinline__ void load_f(gF_cptr Fb, int k, const double (&inv)[P], double (&f)[P])
 {
+    float x[P];
+    load_x<P>(Fb, k, x);
 #pragma unroll
-    for (int i = 0; i < P; i++) f[i] = (double) Fb[(size_t) i * S + k] * inv[i];
+    for (int i = 0; i < P; i++) f[i] = (double) x[i] * inv[i];
 }
 
 // Out of line on purpose: the call has its own register allocation (Gram accumulators + one column in
@@ -802,7 +822,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma clang loop unroll(disable)
     for (int k = tid; k < n; k += NT) {
         double f[P];
-        load_f<P>(Fb, S, k, inv, f);
+        load_f<P>(Fb, k, inv, f);
         gram_add<P>(G, f);
     }
     block_sum_lds<NG, P, NT, gram_t>(G, sm);
@@ -815,17 +835,19 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     const double u0 = 1.0 / sqrt((double) P);
 #pragma unroll
     for (int i = 0; i < P; i++) u[i] = u0;
-    steps += top_eig_wave<P>(sm.tot, u, theta, T == 0);              // u comes back in scalar registers
+    steps += top_eig_wave<P>(sm.tot, u, theta, T == 0);
+#pragma unroll
+    for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
 
 #pragma unroll
     for (int cc = 0; cc < CR; cc++) {                                  // lmbda = zeros (nmf.py:90): a = x
         const int k = cc * NT + tid;
-        if (k < n) load_f<P>(Fb, S, k, inv, lr[cc]);
+        if (k < n) load_f<P>(Fb, k, inv, lr[cc]);
     }
 
     for (int k = NR + tid; k < nLe; k += NT) {                       // lmbda = zeros (nmf.py:90): state a = x
         double f[P], a[PS];
-        load_f<P>(Fb, S, k, inv, f);
+        load_f<P>(Fb, k, inv, f);
 #pragma unroll
         for (int i = 0; i < PS; i++) a[i] = i < P ? f[i] : 0.0;
         lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
@@ -842,7 +864,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             const int k = cc * NT + tid;
             if (k < n) {
                 double f[P];
-                load_f<P>(Fb, S, k, inv, f);
+                load_f<P>(Fb, k, inv, f);
                 col_step<P>(f, lr[cc], u, c, G);
             }
         }
@@ -852,11 +874,18 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         // registers) measured 1.7x SLOWER per column -- the extra live registers end up in AGPRs and every use pays a
         // copy -- and so did a register-resident tier in front of it (tools/trace_stats.py, profiles/round1).
         {
+            // the next column's raw counts (10 VGPRs) are requested before this column's arithmetic starts, so the
+            // L2 latency of the only global read of the tier hides behind ~120 fp64 operations
+            int k = NR + tid;
+            float xq[P];
+            if (k < nLe) load_x<P>(Fb, k, xq);
 #pragma clang loop unroll(disable)
-            for (int k = NR + tid; k < nLe; k += NT) {
+            for (; k < nLe; k += NT) {
                 double f[P], a[PS];
-                load_f<P>(Fb, S, k, inv, f);
                 lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
+#pragma unroll
+                for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
+                load_x<P>(Fb, k + NT < nLe ? k + NT : k, xq);       // unconditional (clamped): no branch around the loads
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
@@ -873,7 +902,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             float xn[P];
             double an[P];
             if (k < n) {
-                load_x<P>(Fb, S, k, xn);
+                load_x<P>(Fb, k, xn);
                 if (t > 0) {
 #pragma unroll
                     for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k]);
@@ -885,7 +914,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma unroll
                 for (int i = 0; i < P; i++) { f[i] = (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
                 if (k + NT < n) {
-                    load_x<P>(Fb, S, k + NT, xn);
+                    load_x<P>(Fb, k + NT, xn);
                     if (t > 0) {
 #pragma unroll
                         for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k + NT]);
@@ -900,6 +929,8 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         { DN_T0(); block_sum_lds<NG, P, NT, gram_t>(G, sm); DN_T1(1); }
         { DN_T0();
         steps += top_eig_wave<P>(sm.tot, u, theta, t == T - 1);      // sigma^2 is only read after the last solve
+#pragma unroll
+        for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
         DN_T1(2); }
     }
 
@@ -912,7 +943,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         const int k = cc * NT + tid;
         if (k < n) {
             double f[P], s, r;
-            load_f<P>(Fb, S, k, inv, f);
+            load_f<P>(Fb, k, inv, f);
             col_final<P>(f, lr[cc], u, first, acc, s, r);
             rs[k] = r;
             if (first) sv[k] = s;
@@ -921,7 +952,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma clang loop unroll(disable)
     for (int k = NR + tid; k < n; k += NT) {
         double f[P], l[P], s, r;
-        load_f<P>(Fb, S, k, inv, f);
+        load_f<P>(Fb, k, inv, f);
         if (k < nLe) {
             double al[PS];
             lds_col_read<PS>(lam + (size_t) (k - NR) * PS, al);
@@ -975,7 +1006,7 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
     const int nL = A.lds_cols;
     char *slot = A.ws + (size_t) blockIdx.x * A.slot_bytes;
     float *Fs = reinterpret_cast<float *>(slot);                      // pristine compacted raw counts  [P][S]
-    float *Fb = Fs + (size_t) P * S;                                  // working copy after bin drops   [P][S]
+    float *Fb = Fs + (size_t) P * S;                                  // working copy after bin drops   [S][P]
     double *Lg = reinterpret_cast<double *>(Fb + (size_t) P * S);     // x + lambda, HBM tier           [P][S]
     double *sv = Lg + (size_t) P * S;                                 // s_start                        [S]
     double *rs = sv + S;                                              // residual profile               [S]
@@ -1049,7 +1080,7 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
 #pragma unroll
                         for (int i = 0; i < P; i++) {
                             Fs[(size_t) i * S + pos] = xv[i];
-                            Fb[(size_t) i * S + pos] = xv[i];
+                            Fb[(size_t) pos * P + i] = xv[i];
                             sumF[i] += f[i];
                         }
                     }
@@ -1169,7 +1200,7 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
                         const int a = k / csize;
                         const int ko = sm.alive[a] * csize + (k - a * csize);
 #pragma unroll
-                        for (int i = 0; i < P; i++) Fb[(size_t) i * S + k] = Fs[(size_t) i * S + ko];
+                        for (int i = 0; i < P; i++) Fb[(size_t) k * P + i] = Fs[(size_t) i * S + ko];
                     }
                     __syncthreads();
                     if (n < 2) { loop_reason = LOOP_VALUE_ERROR; break; }                        // svds ValueError, nmf.py:306-310
