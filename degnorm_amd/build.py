@@ -49,7 +49,7 @@ def build_library(force=False, verbose=False):
     """Compile and link; returns the path of the shared library."""
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    hdr = [os.path.join(CSRC, 'dn_kernels.hpp'), os.path.join(HERE, '..', 'include', 'degnorm_amd.h'),
+    hdr = [os.path.join(CSRC, 'dn_kernels.hpp'), os.path.join(CSRC, 'dn_reduce.hpp'), os.path.join(HERE, '..', 'include', 'degnorm_amd.h'),
            os.path.abspath(__file__)]
     jobs = []
     objs = []

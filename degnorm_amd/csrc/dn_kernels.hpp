@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "dn_reduce.hpp"
 
 // Spill-tier accesses: the x + lambda columns that do not fit on chip are re-read only after a whole pass, far
 // beyond an XCD's L2 share.  The non-temporal forms (DN_SPILL_NT) were measured and did not help (profiles/round1).
@@ -156,73 +157,39 @@ __device__ __forceinline__ double uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
-// Cross-lane moves inside a row of 16 lanes without touching LDS (DPP): quad_perm [1,0,3,2], [2,3,0,1] and
-// row_half_mirror give an all-reduce over each group of 8 lanes in three steps.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double sum8(double s)
-{
-    s += dpp_mov<0xB1>(s);      // quad_perm [1,0,3,2]
-    s += dpp_mov<0x4E>(s);      // quad_perm [2,3,0,1]
-    s += dpp_mov<0x141>(s);     // row_half_mirror: lane i <-> 7 - i of each 8
-    return s;
-}
-
-// Register-only reduce-scatter steps (gfx950 v_permlane32_swap / v_permlane16_swap): two values enter, one leaves.
-//   swap32_add(a, b): lanes 0-31 hold a[l] + a[l+32], lanes 32-63 hold b[l-32] + b[l]
-//   swap16_add(a, b): rows (16 lanes) 0..3 hold a.row0 + a.row1, b.row0 + b.row1, a.row2 + a.row3, b.row2 + b.row3
-typedef unsigned dn_uint2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double swap32_add(double a, double b)
-{
-    const dn_uint2 lo = __builtin_amdgcn_permlane32_swap((unsigned) __double2loint(a), (unsigned) __double2loint(b), false, false);
-    const dn_uint2 hi = __builtin_amdgcn_permlane32_swap((unsigned) __double2hiint(a), (unsigned) __double2hiint(b), false, false);
-    return __hiloint2double((int) hi.x, (int) lo.x) + __hiloint2double((int) hi.y, (int) lo.y);
-}
-__device__ __forceinline__ double swap16_add(double a, double b)
-{
-    const dn_uint2 lo = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(a), (unsigned) __double2loint(b), false, false);
-    const dn_uint2 hi = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(a), (unsigned) __double2hiint(b), false, false);
-    return __hiloint2double((int) hi.x, (int) lo.x) + __hiloint2double((int) hi.y, (int) lo.y);
-}
-
 // Block-wide sum of N register values; the totals are left in sm.tot[0..N), bit-identical for every reader
-// (the wave-uniform branches of the state machine rely on that).
-// Per wave, in registers only: a reduce-scatter over the four 16-lane rows (pairs of entries through
-// v_permlane32_swap, pairs of those through v_permlane16_swap: N values -> N/4 registers whose row r holds entry
-// 4k + {0,2,1,3}[r] summed over lanes {l, l+16, l+32, l+48}), then a 4-step DPP all-reduce inside each row.
-// ~5.4 VALU ops per value and no LDS traffic; the summation order is fixed.  Then one cross-wave add through LDS.
+// (the wave-uniform branches of the state machine rely on that).  Per wave the values are reduce-scattered in
+// registers (dn_reduce.hpp: lane l ends up with the wave total of entry bitrev6(l)), one LDS write per lane hands
+// them to the cross-wave add.
 template <int N, int P, int NT, typename VT>
 __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm)
 {
-    static_assert(N <= Smem<P, NT>::NX, "xw too small");
+    static_assert(N <= Smem<P, NT>::NX && N <= 128, "xw too small");
     constexpr int W = NT / 64;
-    constexpr int R1 = (N + 1) / 2, R2 = (R1 + 1) / 2;
     const int lane = lane_id(), w = wave_id();
     double *dst = (W > 1) ? sm.xw[w] : sm.tot;
-    double h[R1];
+    const int e = reduce_scatter_entry(lane);
+    if constexpr (N <= 64) {
+        const double s = wave_reduce_scatter<N, VT>(g, lane);
+        if (e < N) dst[e] = s;
+    } else {                                                           // p = 11, 12: 66 / 78 Gram entries, two rounds
+        VT lo[64], hi[N - 64];
 #pragma unroll
-    for (int j = 0; j < R1; j++) h[j] = swap32_add((double) g[2 * j], 2 * j + 1 < N ? (double) g[2 * j + 1] : 0.0);
-    const int row = lane >> 4;
-    const int sub = ((row & 1) << 1) | (row >> 1);
+        for (int i = 0; i < 64; i++) lo[i] = g[i];
 #pragma unroll
-    for (int k = 0; k < R2; k++) {
-        double s = swap16_add(h[2 * k], 2 * k + 1 < R1 ? h[2 * k + 1] : 0.0);
-        s = sum8(s);
-        s += dpp_mov<0x140>(s);     // row_mirror: lane i <-> 15 - i
-        if ((lane & 15) == 0 && 4 * k + sub < N) dst[4 * k + sub] = s;
+        for (int i = 64; i < N; i++) hi[i - 64] = g[i];
+        const double s0 = wave_reduce_scatter<64, VT>(lo, lane);
+        const double s1 = wave_reduce_scatter<N - 64, VT>(hi, lane);
+        dst[e] = s0;
+        if (e < N - 64) dst[64 + e] = s1;
     }
     if constexpr (W > 1) {
         __syncthreads();
         if (threadIdx.x < N) {
-            double s = sm.xw[0][threadIdx.x];
+            double t = sm.xw[0][threadIdx.x];
 #pragma unroll
-            for (int ww = 1; ww < W; ww++) s += sm.xw[ww][threadIdx.x];
-            sm.tot[threadIdx.x] = s;
+            for (int ww = 1; ww < W; ww++) t += sm.xw[ww][threadIdx.x];
+            sm.tot[threadIdx.x] = t;
         }
     }
     __syncthreads();
