@@ -120,9 +120,11 @@ template <int P, int NT>
 struct Smem {
     static constexpr int W = NT / 64;
     static constexpr int NG = P * (P + 1) / 2;
-    static constexpr int NX = NG > 64 ? NG : 64;
+    static constexpr int NX = NG >= 64 ? NG + 2 : 64;
+    static constexpr int ZSLOT = NX - 1;     // tot[ZSLOT] is written once (0.0): the load target of padding lanes
     double xw[W][NX];                        // per-wave totals (cross-wave combine)
     double tot[NX];                          // block totals (broadcast)
+    double dsel[NX];                         // 1.0 at the packed indices of the Gram diagonal, else 0.0
     double ss[MAX_BINS];                     // per-bin mean squared residual
     int32_t alive[MAX_BINS];                 // original ids of the surviving bins, in order
     int32_t cnt[W];                          // per-wave hi-coverage counts
@@ -161,16 +163,18 @@ __device__ __forceinline__ double uniform(double v)
 // (the wave-uniform branches of the state machine rely on that).  Per wave the values are reduce-scattered in
 // registers (dn_reduce.hpp: lane l ends up with the wave total of entry bitrev6(l)), one LDS write per lane hands
 // them to the cross-wave add.
-template <int N, int P, int NT, typename VT>
-__device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm)
+template <int N, int P, int NT, typename VT, bool SHIFT = false>
+__device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm, double diag_shift = 0.0)
 {
     static_assert(N <= Smem<P, NT>::NX && N <= 128, "xw too small");
+    static_assert(!SHIFT || N == P * (P + 1) / 2, "the shift is for the packed Gram matrix");
     constexpr int W = NT / 64;
     const int lane = lane_id(), w = wave_id();
     double *dst = (W > 1) ? sm.xw[w] : sm.tot;
     const int e = reduce_scatter_entry(lane);
     if constexpr (N <= 64) {
-        const double s = wave_reduce_scatter<N, VT>(g, lane);
+        double s = wave_reduce_scatter<N, VT>(g, lane);
+        if constexpr (SHIFT && W == 1) { if (e < N) s = fma(-diag_shift, sm.dsel[e], s); }
         if (e < N) dst[e] = s;
     } else {                                                           // p = 11, 12: 66 / 78 Gram entries, two rounds
         VT lo[64], hi[N - 64];
@@ -178,8 +182,9 @@ __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm)
         for (int i = 0; i < 64; i++) lo[i] = g[i];
 #pragma unroll
         for (int i = 64; i < N; i++) hi[i - 64] = g[i];
-        const double s0 = wave_reduce_scatter<64, VT>(lo, lane);
-        const double s1 = wave_reduce_scatter<N - 64, VT>(hi, lane);
+        double s0 = wave_reduce_scatter<64, VT>(lo, lane);
+        double s1 = wave_reduce_scatter<N - 64, VT>(hi, lane);
+        if constexpr (SHIFT && W == 1) { s0 = fma(-diag_shift, sm.dsel[e], s0); if (e < N - 64) s1 = fma(-diag_shift, sm.dsel[64 + e], s1); }
         dst[e] = s0;
         if (e < N - 64) dst[64 + e] = s1;
     }
@@ -189,6 +194,7 @@ __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm)
             double t = sm.xw[0][threadIdx.x];
 #pragma unroll
             for (int ww = 1; ww < W; ww++) t += sm.xw[ww][threadIdx.x];
+            if constexpr (SHIFT) t = fma(-diag_shift, sm.dsel[threadIdx.x], t);     // G - mu I for the eigen-solver
             sm.tot[threadIdx.x] = t;
         }
     }
@@ -303,98 +309,7 @@ __device__ __forceinline__ int top_eig(const double (&G)[P * (P + 1) / 2], doubl
     return steps;
 }
 
-// Row-distributed form of the same iteration, used by the hot loop.  After block_sum_lds the Gram totals sit in
-// LDS; lane l keeps only row (l & 15) of G, computes one component of G v per step and the p components are
-// broadcast back through v_readlane into scalar registers (v is wave-uniform).  A step is then p FMAs + 2p
-// readlanes instead of p^2 FMAs in every lane.  Two unnormalised steps run between convergence checks
-// (fp64 range absorbs the growth); the check predicts the current error from the contraction seen between
-// consecutive checks and stops at ~1e-13.  All waves run it redundantly on identical data.
-template <int P>
-__device__ __forceinline__ void bcast_rows(double y, double (&yb)[P])
-{
-    const int lo = __double2loint(y), hi = __double2hiint(y);
-#pragma unroll
-    for (int j = 0; j < P; j++)
-        yb[j] = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
-}
-
-template <int P>
-__device__ __forceinline__ double row_dot(const double (&Gr)[P], const double (&v)[P])
-{
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int j = 0; j + 1 < P; j += 2) { a0 = fma(Gr[j], v[j], a0); a1 = fma(Gr[j + 1], v[j + 1], a1); }
-    if (P & 1) a0 = fma(Gr[P - 1], v[P - 1], a0);
-    return a0 + a1;
-}
-
-template <int P>
-__device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], double &theta)
-{
-    static_assert(P <= 16, "row-distributed solver maps rows to the 16 lanes of a DPP row");
-    const int r = (lane_id() & 15) < P ? (lane_id() & 15) : P - 1;
-    double Gr[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-        const int a = r > j ? r : j, b = r > j ? j : r;
-        Gr[j] = tot[a * (a + 1) / 2 + b];
-    }
-    double tr = 0.0;
-#pragma unroll
-    for (int i = 0; i < P; i++) tr += tot[i * (i + 1) / 2 + i];
-
-    double v[P], w[P];
-    bcast_rows<P>(row_dot<P>(Gr, u), w);                               // w = G u
-    double th = 0.0;
-#pragma unroll
-    for (int i = 0; i < P; i++) th = fma(u[i], w[i], th);
-    if (!(th > 0.0)) { theta = 0.0; return 1; }
-    double mu = (tr - th) * (1.0 / (double) (P > 1 ? P - 1 : 1));
-    mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
-#pragma unroll
-    for (int j = 0; j < P; j++) Gr[j] = (j == r) ? Gr[j] - mu : Gr[j];  // G - mu I
-#pragma unroll
-    for (int i = 0; i < P; i++) v[i] = fma(-mu, u[i], w[i]);             // first shifted step
-    int steps = 1;
-    double d2_prev = -1.0;
-    for (;;) {
-        double n2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; i++) n2 = fma(v[i], v[i], n2);
-        if (!(n2 > 0.0)) { theta = 0.0; return steps; }
-        // 1/sqrt(n2): hardware estimate + two Newton steps (only the direction of v matters; u.u = 1 to round-off)
-        double inv = __builtin_amdgcn_rsq(n2);
-        inv = inv * fma(-0.5 * n2 * inv, inv, 1.5);
-        inv = inv * fma(-0.5 * n2 * inv, inv, 1.5);
-        double d2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; i++) {
-            const double un = v[i] * inv;
-            const double d = un - u[i];
-            d2 = fma(d, d, d2);
-            u[i] = un;
-        }
-        // contraction between checks: d2 / d2_prev ~ rho^(2 * steps between checks); predicted current error^2 ~ d2 * ratio
-        bool done = d2 <= 1e-26;
-        if (d2_prev > 0.0) {
-            const double ratio = d2 / d2_prev;
-            if (ratio < 0.25 && 4.0 * d2 * ratio <= 1e-26) done = true;
-        }
-        if (done || steps >= 4000) break;
-        d2_prev = d2;
-        bcast_rows<P>(row_dot<P>(Gr, u), w);                           // two plain steps, no normalisation in between
-        bcast_rows<P>(row_dot<P>(Gr, w), v);
-        steps += 2;
-    }
-    bcast_rows<P>(row_dot<P>(Gr, u), w);                               // Rayleigh quotient of the unshifted matrix
-    th = mu;
-#pragma unroll
-    for (int i = 0; i < P; i++) th = fma(u[i], w[i], th);
-    theta = th;
-    return steps + 1;
-}
-
-// The same eigenpair through the fp64 matrix cores: repeated squaring instead of single power steps.
+// The hot loop finds the same eigenpair through the fp64 matrix cores: repeated squaring instead of single power steps.
 // v_mfma_f64_16x16x4_f64 (gfx950, 64 cycles) takes A as lane (i = l & 15, k = l >> 4) -> A[i][k], B as lane
 // (j, k) -> B[k][j] and returns D[q + 4 r][j] in register r of lane (j, q = l >> 4).  For a symmetric matrix
 // held as h[kb] = H[l & 15][(l >> 4) + 4 kb] the product H H = sum_kb mfma(h[kb], h[kb]) therefore comes back in
@@ -433,39 +348,46 @@ __device__ __forceinline__ dn_double4 mfma_sym(const double (&h)[KB], const doub
     return y;
 }
 
+// State carried from one solve to the next inside an nmf() call: the iterate in the MFMA B layout (no rebuild
+// from the broadcast u), and the scale / shift the next solve starts from (they only steer convergence).
 template <int P>
-__device__ __forceinline__ int top_eig_mfma(const double *tot, double (&u)[P], double &theta, bool exact_theta)
+struct EigState {
+    static constexpr int KB = (P + 3) / 4;
+    double v[KB];        // v[kb] of lane group q = u[q + 4 kb]
+    double sc;           // ~ 1 / trace(G)
+    double mu;           // shift in the units of G (0: none); the caller subtracts it from the diagonal in LDS
+};
+
+template <int P>
+__device__ __forceinline__ void eig_state_cold(EigState<P> &st, double tr)
+{
+    const int q = lane_id() >> 4;
+    const double u0 = 1.0 / sqrt((double) P);
+#pragma unroll
+    for (int kb = 0; kb < EigState<P>::KB; kb++) st.v[kb] = (q + 4 * kb < P) ? u0 : 0.0;
+    st.sc = __builtin_amdgcn_rcp(tr);
+    st.mu = 0.0;
+}
+
+// tot holds G - st.mu I (packed, plus a zero at zslot).  On return u is the unit top eigenvector (broadcast),
+// theta the eigenvalue of G: exact (Rayleigh quotient) when asked for, else an estimate that only feeds the next shift.
+template <int P>
+__device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double (&u)[P], double &theta, EigState<P> &st,
+                                            bool exact_theta)
 {
     static_assert(P <= 16, "one 16 x 16 MFMA tile");
-    constexpr int KB = (P + 3) / 4;
+    constexpr int KB = EigState<P>::KB;
     constexpr int M = DN_EIG_SQUARINGS;
     const int c = lane_id() & 15, q = lane_id() >> 4;
+    const double sc = st.sc, mu = st.mu;
     double g[KB], h[KB], v[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
         const int k = q + 4 * kb;
-        const bool valid = c < P && k < P;
         const int a = c > k ? c : k, b = c > k ? k : c;
-        const double t = tot[valid ? a * (a + 1) / 2 + b : 0];
-        g[kb] = valid ? t : 0.0;
-    }
-    double dg[P];
-#pragma unroll
-    for (int i = 0; i < P; i++) dg[i] = tot[i * (i + 1) / 2 + i];
-#pragma unroll
-    for (int w = 1; w < P; w *= 2) {                                   // pairwise tree: short dependency chain
-#pragma unroll
-        for (int i = 0; i + w < P; i += 2 * w) dg[i] += dg[i + w];
-    }
-    const double tr = dg[0];
-    if (!(tr > 0.0)) { theta = 0.0; return 1; }
-    const double sc = __builtin_amdgcn_rcp(tr);                        // only a scale: the estimate is good enough
-    double mu = (tr - theta) * (1.0 / (double) (P > 1 ? P - 1 : 1));
-    mu = (theta > 0.0 && mu > 0.0 && mu < 0.5 * theta) ? mu * sc : 0.0;
-#pragma unroll
-    for (int kb = 0; kb < KB; kb++) {
-        g[kb] *= sc;
-        h[kb] = (c == q + 4 * kb && c < P) ? g[kb] - mu : g[kb];      // rows / columns >= P are zero and stay zero
+        g[kb] = tot[a < P ? a * (a + 1) / 2 + b : zslot] * sc;          // rows / columns >= P are zero and stay zero
+        h[kb] = g[kb];
+        v[kb] = st.v[kb];
     }
 #pragma unroll
     for (int m = 0; m < M; m++) {
@@ -473,20 +395,22 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, double (&u)[P], d
 #pragma unroll
         for (int kb = 0; kb < KB; kb++) h[kb] = d[kb];
     }
-#pragma unroll
-    for (int kb = 0; kb < KB; kb++) {
-        double w = 0.0;
-#pragma unroll
-        for (int qq = 0; qq < 4; qq++)
-            if (qq + 4 * kb < P) w = (q == qq) ? u[qq + 4 * kb] : w;
-        v[kb] = w;
-    }
     // two steps back to back; the norm of the first iterate is formed in the shadow of the second product
     const dn_double4 y1 = mfma_sym<KB>(h, v);
     double y1r[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) y1r[kb] = y1[kb];
     const dn_double4 y2 = mfma_sym<KB>(h, y1r);
+    // trace of G for the next solve's scale and shift: independent of the products above
+    double dg[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) dg[i] = tot[i * (i + 1) / 2 + i];
+#pragma unroll
+    for (int w = 1; w < P; w *= 2) {
+#pragma unroll
+        for (int i = 0; i + w < P; i += 2 * w) dg[i] += dg[i + w];
+    }
+    const double tr = fma((double) P, mu, dg[0]);
     double p1 = 0.0, p2 = 0.0;
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) { p1 = fma(y1[kb], y1[kb], p1); p2 = fma(y2[kb], y2[kb], p2); }
@@ -534,32 +458,24 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, double (&u)[P], d
                                 __builtin_amdgcn_readlane(__double2loint(t), 16 * (i & 3)));
     }
     if (exact_theta) {
-        const dn_double4 w = mfma_sym<KB>(g, v);                       // Rayleigh quotient of the unshifted matrix
+        const dn_double4 w = mfma_sym<KB>(g, v);                       // Rayleigh quotient: v^T (G - mu I) v / |v|^2 + mu
         double tp = 0.0;
 #pragma unroll
         for (int kb = 0; kb < KB; kb++) tp = fma(v[kb], w[kb], tp);
-        theta = allsum_rows(tp) * tr;
+        theta = allsum_rows(tp) / sc + mu;
     } else {
-        // only the next solve's shift reads it: dominant eigenvalue of H ~ |H y| / |y|, and H = ((G - mu I) / tr)^(2^M)
+        // dominant eigenvalue of H ~ |H y| / |y|, and H = ((G - mu I) sc)^(2^M)
         double lam = n_last * i_prev;
 #pragma unroll
         for (int m = 0; m < M; m++) lam = __builtin_amdgcn_sqrt(lam);
-        theta = (lam + mu) * tr;
+        theta = fma(lam, __builtin_amdgcn_rcp(sc), mu);
     }
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) st.v[kb] = v[kb];
+    st.sc = __builtin_amdgcn_rcp(tr);
+    double mn = (tr - theta) * (1.0 / (double) (P > 1 ? P - 1 : 1));
+    st.mu = (theta > 0.0 && mn > 0.0 && mn < 0.5 * theta) ? mn : 0.0;
     return steps + 1;
-}
-
-#ifndef DN_EIG_MFMA
-#define DN_EIG_MFMA 1
-#endif
-template <int P>
-__device__ __forceinline__ int top_eig_wave(const double *tot, double (&u)[P], double &theta, bool exact_theta)
-{
-#if DN_EIG_MFMA
-    return top_eig_mfma<P>(tot, u, theta, exact_theta);
-#else
-    return top_eig_rows<P>(tot, u, theta);
-#endif
 }
 
 typedef DN_GRAM_T gram_t;      // per-lane Gram accumulators: double (exact mode) or float (mixed mode)
@@ -799,10 +715,14 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         for (int i = 0; i < P; i++) tr += sm.tot[i * (i + 1) / 2 + i];
         if (!(tr > 0.0)) { if (tid == 0) g_gs.status = ST_ARPACK; __syncthreads(); return; }
     }
-    const double u0 = 1.0 / sqrt((double) P);
+    EigState<P> est;
+    {
+        double tr = 0.0;
 #pragma unroll
-    for (int i = 0; i < P; i++) u[i] = u0;
-    steps += top_eig_wave<P>(sm.tot, u, theta, T == 0);
+        for (int i = 0; i < P; i++) tr += sm.tot[i * (i + 1) / 2 + i];
+        eig_state_cold<P>(est, tr);
+    }
+    steps += top_eig_mfma<P>(sm.tot, Smem<P, NT>::ZSLOT, u, theta, est, T == 0);
 #pragma unroll
     for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
 
@@ -893,9 +813,9 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             }
         }
         DN_T1(0); }
-        { DN_T0(); block_sum_lds<NG, P, NT, gram_t>(G, sm); DN_T1(1); }
+        { DN_T0(); block_sum_lds<NG, P, NT, gram_t, true>(G, sm, est.mu); DN_T1(1); }       // tot = G - mu I
         { DN_T0();
-        steps += top_eig_wave<P>(sm.tot, u, theta, t == T - 1);      // sigma^2 is only read after the last solve
+        steps += top_eig_mfma<P>(sm.tot, Smem<P, NT>::ZSLOT, u, theta, est, t == T - 1);   // sigma^2 is only read after the last solve
 #pragma unroll
         for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
         DN_T1(2); }
@@ -978,6 +898,13 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
     double *sv = Lg + (size_t) P * S;                                 // s_start                        [S]
     double *rs = sv + S;                                              // residual profile               [S]
     if (tid < P) gs.inv[tid] = A.inv_scale[tid];
+    for (int t = tid; t < Smem<P, NT>::NX; t += NT) {                  // constants of the eigen-solver (top_eig_mfma)
+        bool diag = false;
+#pragma unroll
+        for (int i = 0; i < P; i++) diag = diag || (t == i * (i + 1) / 2 + i);
+        sm.dsel[t] = diag ? 1.0 : 0.0;
+        if (t == Smem<P, NT>::ZSLOT) sm.tot[t] = 0.0;
+    }
 
     for (;;) {
         if (tid == 0) sm.gene = atomicAdd(A.counter, 1);
