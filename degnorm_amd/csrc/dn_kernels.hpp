@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "dn_reduce.hpp"
 
 // Spill-tier accesses: the x + lambda columns that do not fit on chip are re-read only after a whole pass, far
@@ -480,7 +481,7 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
 
 typedef DN_GRAM_T gram_t;      // per-lane Gram accumulators: double (exact mode) or float (mixed mode)
 
-template <int P, typename T>
+template <int P, typename T, bool INIT = false>     // INIT: G = a a^T (first column of a pass: no zeroing needed)
 __device__ __forceinline__ void gram_add(T (&G)[P * (P + 1) / 2], const double (&a)[P])
 {
     T b[P];
@@ -489,7 +490,7 @@ __device__ __forceinline__ void gram_add(T (&G)[P * (P + 1) / 2], const double (
 #pragma unroll
     for (int i = 0; i < P; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = fma(b[i], b[j], G[i * (i + 1) / 2 + j]);
+        for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = INIT ? b[i] * b[j] : fma(b[i], b[j], G[i * (i + 1) / 2 + j]);
 }
 
 template <int P> __device__ __forceinline__ double vmax(const double (&v)[P])
@@ -573,7 +574,7 @@ typedef double __attribute__((address_space(1))) *gdouble_ptr;
 //     lambda' = max(lambda - c (K E - x), 0)   (nmf.py:94-96)   <=>   a' = x + lambda' = max(a - c (u s - x), x),
 // with s = u . a (E_j sigma), so a pass costs 3 fp64 ops per element plus the p(p+1)/2 Gram products and
 // x + lambda is never re-formed (nmf.py:97).  lambda is not needed by itself anywhere.
-template <int P>
+template <int P, bool INIT = false>
 __device__ __forceinline__ void col_step(const double (&f)[P], double (&a)[P], const double (&u)[P], double c,
                                          gram_t (&G)[P * (P + 1) / 2])
 {
@@ -587,7 +588,7 @@ __device__ __forceinline__ void col_step(const double (&f)[P], double (&a)[P], c
         const double res = fma(u[i], s, -f[i]);                        // est - x                       nmf.py:94
         a[i] = fmax(fma(-c, res, a[i]), f[i]);                         // x + max(lambda - c res, 0)    nmf.py:95-97
     }
-    gram_add<P>(G, a);
+    gram_add<P, gram_t, INIT>(G, a);
 }
 
 template <int P>
@@ -742,8 +743,10 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
+        if constexpr (CR > 0) {
 #pragma unroll
-        for (int i = 0; i < NG; i++) G[i] = 0.0;
+            for (int i = 0; i < NG; i++) G[i] = 0.0;
+        }
         { DN_T0();
         // register tier
 #pragma unroll
@@ -756,18 +759,18 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             }
         }
         // LDS tier.  Column o keeps its p doubles contiguously (stride PS = p rounded up to even, 16-B aligned):
-        // 128-bit LDS accesses, conflict-free because the lane stride (20 dwords at p = 10) is 4 x odd.  Deliberately
-        // plain: an explicitly software-pipelined version of this loop (next column's counts and state prefetched into
-        // registers) measured 1.7x SLOWER per column -- the extra live registers end up in AGPRs and every use pays a
-        // copy -- and so did a register-resident tier in front of it (tools/trace_stats.py, profiles/round1).
+        // 128-bit LDS accesses, conflict-free because the lane stride (20 dwords at p = 10) is 4 x odd.
+        // The next column's raw counts (10 VGPRs) are requested before this column's arithmetic starts, so the L2
+        // latency of the only global read of the tier hides behind ~120 fp64 operations.  Prefetching the fp64 state
+        // as well measured 1.7x SLOWER per column -- the extra live registers end up in AGPRs and every use pays a copy
+        // -- and so did a register-resident tier in front of it (tools/trace_stats.py, profiles/round1).
+        // A lane's first column of the pass starts the Gram accumulators (G = a a^T) instead of zeroing 55 of them.
         {
-            // the next column's raw counts (10 VGPRs) are requested before this column's arithmetic starts, so the
-            // L2 latency of the only global read of the tier hides behind ~120 fp64 operations
             int k = NR + tid;
             float xq[P];
             if (k < nLe) load_x<P>(Fb, k, xq);
-#pragma clang loop unroll(disable)
-            for (; k < nLe; k += NT) {
+            auto column = [&](auto first_tag) {
+                constexpr bool FIRST = decltype(first_tag)::value;
                 double f[P], a[PS];
                 lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
 #pragma unroll
@@ -776,11 +779,20 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
-                col_step<P>(f, aa, u, c, G);
+                col_step<P, FIRST>(f, aa, u, c, G);
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
                 lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
+            };
+            if constexpr (CR == 0) {
+                if (k < nLe) { column(std::true_type{}); k += NT; }
+                else {
+#pragma unroll
+                    for (int i = 0; i < NG; i++) G[i] = 0.0;
+                }
             }
+#pragma clang loop unroll(disable)
+            for (; k < nLe; k += NT) column(std::false_type{});
         }
         // spill tier: x + lambda of the columns that do not fit in LDS lives in the slot (L2 / Infinity Cache).
         // Here the loads are far away, and prefetching the next column's counts and state does pay (1.15x).
