@@ -256,11 +256,11 @@ static int finish_upload(dn_handle h, const float *host_packed)
         const dn::KernelSet *narrow = (h->ks->p != 0) ? dn::kernel_set_narrow(p) : nullptr;
         if (env) h->split_len = atoi(env);
         else if (narrow) {
-            // narrow class = genes up to ~3.1x the columns its workgroups can keep in LDS (measured flat optimum
-            // 2300-3200 bases at p = 10, where a 128-thread workgroup holds 860 columns: profiles/round1)
+            // narrow class = genes up to ~2.1x the columns its workgroups can keep in LDS (measured optimum 2 000-2 200
+            // bases at p = 10, where a 128-thread workgroup holds 975 columns: profiles/round1/README.md)
             const int per_cu_n = std::max(1, narrow->blocks_per_cu(0));
             const int64_t lds_n = (160 * 1024) / per_cu_n - (int64_t) narrow->static_lds_bytes - 256;
-            h->split_len = (int32_t) std::max<int64_t>(0, (int64_t) (3.1 * (double) (lds_n / (8 * (int64_t) (p + (p & 1))))));
+            h->split_len = (int32_t) std::max<int64_t>(0, (int64_t) (2.1 * (double) (lds_n / (8 * (int64_t) (p + (p & 1))))));
         }
         if (!narrow) h->split_len = 0;
         std::vector<int32_t> ord[2];
@@ -278,7 +278,7 @@ static int finish_upload(dn_handle h, const float *host_packed)
             if (per_cu < 1) per_cu = 1;
             C.slots = (int) std::min<int64_t>(C.n, (int64_t) per_cu * h->n_cus);
             C.S = (h->glen[ord[c][0]] + 63) & ~63;                    // longest gene of the class
-            // slot: Fs, Fb (fp32 [p][S]) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
+            // slot: Fs, Fb (fp32, p x S) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
             C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double));
             {
                 // one very long gene sizes every slot of its class: keep the scratch within a share of free HBM by

@@ -24,7 +24,8 @@
 #include "dn_reduce.hpp"
 
 // Spill-tier accesses: the x + lambda columns that do not fit on chip are re-read only after a whole pass, far
-// beyond an XCD's L2 share.  The non-temporal forms (DN_SPILL_NT) were measured and did not help (profiles/round1).
+// beyond an XCD's L2 share.  The non-temporal forms (DN_SPILL_NT) were measured and did not help, and neither did a
+// column-contiguous layout with 128-bit accesses (80-B lane stride: 1.25x slower than these row-wise 8-B ones).
 #ifndef DN_SPILL_NT
 #define DN_SPILL_LOAD(p) (*(p))
 #define DN_SPILL_STORE(v, p) (*(p) = (v))
