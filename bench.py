@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # AMD MI355X spec, fp64 vector (= 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz); not in the guide
 
 
 def algorithmic_bytes(trace, lengths, p, nmf_iter, mask=None):
@@ -41,18 +42,18 @@ def algorithmic_bytes(trace, lengths, p, nmf_iter, mask=None):
     return float(per_gene[mask].sum() if mask is not None else per_gene.sum())
 
 
-def pmc_traffic(kernel_name):
+def pmc_traffic(kernel_name, genes_in_kernel):
     """
     HBM bytes per k_baseline launch from the PMC counters.  bench.py cannot collect PMCs itself: the figure comes
     from the committed rocprofv3 passes of THIS command (profiles/round1/pmc_traffic.json: separate --pmc
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 calibration) and is only reported when the
-    profiled kernel is the one that just ran.
+    profiled kernel (name and gene class) is the one that just ran.
     """
     path = os.path.join(ROOT, 'profiles', 'round1', 'pmc_traffic.json')
     try:
         with open(path) as f:
             d = json.load(f)
-        if d.get('kernel') == kernel_name:
+        if d.get('kernel') == kernel_name and int(d.get('genes_in_kernel', -1)) == int(genes_in_kernel):
             return float(d['hbm_bytes_per_launch'])
     except (OSError, ValueError, KeyError):
         pass
@@ -170,6 +171,11 @@ def main():
         avg_ms = float(np.mean(kernel_ms))
         avg_bytes = float(np.mean(alg_bytes))
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(eng.dev.class_kernel_name(0), int(wide.sum())) if (world == 1 and args.genes == 20000) else None
+        # fp64 vector work of the inner passes: per column and inner iteration u.a (2p), the update (5p), the Gram
+        # update (p(p+1)) and the 1/s scaling (p) -- the unit that actually bounds the kernel ("What bounds it")
+        col_iters = float(np.mean([float(tr[wide, 2].astype(np.float64).sum()) * args.nmf_iter for tr in eng.traces]))
+        flop = col_iters * (p * p + 9.0 * p)
         out = {
             'metric': 'genes/sec (20k genes x 10 samples, 5 iters)',
             'value': value, 'unit': 'genes/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -181,7 +187,12 @@ def main():
                        'genes_per_gpu': len(my_genes), 'sharding': 'contiguous gene chunks, 1 all-reduce of 3p+1 f64 per outer iter'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
-                         'traffic': pmc_traffic(eng.dev.class_kernel_name(0)) if (world == 1 and args.genes == 20000) else None,
+                         'traffic': traffic,
+                         'traffic_rate_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                         'traffic_frac': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         'fp64_valu': {'achieved': flop / (avg_ms * 1e-3) / 1e12, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                       'frac': flop / (avg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                       'flop_per_column_iteration': p * p + 9.0 * p},
                          'kernel': eng.dev.class_kernel_name(0), 'avg_launch_ms': avg_ms,
                          'algorithmic_bytes_per_launch': avg_bytes, 'launches_timed': len(kernel_ms),
                          'genes_in_kernel': int(wide.sum()), 'split_length': split,
@@ -189,7 +200,10 @@ def main():
                                            'algorithmic_bytes_per_launch': float(np.mean(alg_all)) - avg_bytes,
                                            'launch_to_end_ms': float(np.mean(narrow_ms)),
                                            'note': 'narrow genes, 128-thread workgroups, fills CUs as the wide class drains'},
-                         'note': 'rank-0 shard; HIP events on the library stream around each launch'},
+                         'note': 'rank-0 shard; HIP events on the library stream around each launch.  achieved = algorithmic '
+                                 'bytes of SURVEY 8(d) (fp32 x and lambda re-streamed every inner iteration) / time: the kernel keeps '
+                                 'x + lambda of the first ~2000 columns of a gene in LDS, so this figure can exceed the HBM peak; '
+                                 'traffic* = what the fabric-side counters saw'},
             'setup': {'synth_s': t_gen, 'upload_s': t_up},
         }
         if world == 1 and args.cpu_sample > 0:

@@ -1,0 +1,88 @@
+"""
+Condenses a tools/profile_round.sh output directory into the files kept under profiles/<round>/:
+per-kernel FETCH_SIZE / WRITE_SIZE summaries, the kernel stats, and pmc_traffic.json (HBM-side bytes per launch of the
+dominant kernel, FETCH_SIZE doubled as calibrated in profiles/round1/pmc_calibration_*.csv and prescribed for gfx950 by
+the MI355X guide).  Usage: python tools/pmc_summary.py gpurun_out/<dir> profiles/round1 <prefix>
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    rows = defaultdict(lambda: defaultdict(float))        # kernel -> dispatch -> summed value
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r['Counter_Name'] == counter:
+                rows[r['Kernel_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
+    return {k: list(v.values()) for k, v in rows.items()}
+
+
+def write_summary(per, out):
+    with open(out, 'w') as fh:
+        fh.write('kernel,dispatches,mean_KiB,min_KiB,max_KiB\n')
+        for k, v in per.items():
+            fh.write('"{0}",{1},{2:.3f},{3:.3f},{4:.3f}\n'.format(k, len(v), sum(v) / len(v), min(v), max(v)))
+
+
+def spaced(name):
+    """k_baseline<10,256,0> -> k_baseline<10, 256, 0> (how rocprofv3 prints template arguments)."""
+    inner = name[name.index('<') + 1:-1].split(',')
+    return name[:name.index('<') + 1] + ', '.join(inner) + '>'
+
+
+def mean_of(per, needle):
+    for k, v in per.items():
+        if needle in k:
+            return sum(v) / len(v)
+    return 0.0
+
+
+def main():
+    src, dst, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
+    fetch = per_kernel(os.path.join(src, 'fetch', 'run_counter_collection.csv'), 'FETCH_SIZE')
+    write = per_kernel(os.path.join(src, 'write', 'run_counter_collection.csv'), 'WRITE_SIZE')
+    write_summary(fetch, os.path.join(dst, prefix + 'pmc_fetch_size_per_kernel.csv'))
+    write_summary(write, os.path.join(dst, prefix + 'pmc_write_size_per_kernel.csv'))
+    shutil.copy(os.path.join(src, 'stats', 'run_kernel_stats.csv'), os.path.join(dst, prefix + 'kernel_stats.csv'))
+    with open(os.path.join(src, 'stats', 'run_kernel_trace.csv')) as fh, \
+            open(os.path.join(dst, prefix + 'kernel_trace_baseline.csv'), 'w') as out:
+        for i, line in enumerate(fh):
+            if i == 0 or 'dn::k_' in line:
+                out.write(line)
+    shutil.copy(os.path.join(src, 'bench.json'), os.path.join(dst, prefix + 'bench.json'))
+
+    bench = json.load(open(os.path.join(src, 'bench.json')))
+    name = bench['roofline']['kernel']                               # e.g. k_baseline<10,256,0>
+    wide = spaced(name)
+    narrow_name = bench['roofline'].get('second_kernel', {}).get('kernel', '')
+    f_w, w_w = mean_of(fetch, wide), mean_of(write, wide)
+    traffic = {
+        'method': 'tools/profile_round.sh: rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py '
+                  '--warmup 0 --cpu-sample 0 (separate passes for FETCH_SIZE and WRITE_SIZE; values in KiB; FETCH_SIZE doubled: '
+                  'on gfx950 it reports 1/2 of the bytes of coalesced reads -- MI355X guide, and calibrated here with '
+                  'tools/ubench/stream_read.hip: 0.500 for 4-B and 8-B-per-lane reads, WRITE_SIZE 1.000)',
+        'kernel': name,
+        'split_length': bench['roofline'].get('split_length'),
+        'genes_in_kernel': bench['roofline'].get('genes_in_kernel'),
+        'FETCH_SIZE_KiB_per_launch': f_w,
+        'WRITE_SIZE_KiB_per_launch': w_w,
+        'read_bytes_per_launch': 2.0 * f_w * 1024.0,
+        'write_bytes_per_launch': w_w * 1024.0,
+        'hbm_bytes_per_launch': 2.0 * f_w * 1024.0 + w_w * 1024.0,
+    }
+    if narrow_name:
+        narrow = spaced(narrow_name)
+        traffic['FETCH_SIZE_KiB_per_launch_narrow_kernel'] = mean_of(fetch, narrow)
+        traffic['WRITE_SIZE_KiB_per_launch_narrow_kernel'] = mean_of(write, narrow)
+        traffic['hbm_bytes_per_launch_narrow_kernel'] = (2.0 * mean_of(fetch, narrow) + mean_of(write, narrow)) * 1024.0
+    with open(os.path.join(dst, 'pmc_traffic.json'), 'w') as fh:
+        json.dump(traffic, fh, indent=1)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == '__main__':
+    main()
