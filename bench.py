@@ -109,7 +109,7 @@ def main():
     import torch
     from degnorm_amd import synth
     from degnorm_amd.nmf_mpi import ShardedNMFOA, TorchComm, LocalComm
-    from degnorm_amd.utils import split_into_chunks
+    from degnorm_amd.utils import partition_by_length
 
     torch.cuda.set_device(local_rank)
     comm = LocalComm()
@@ -121,7 +121,9 @@ def main():
 
     cfg = dict(synth.CONFIGS['c2'])
     p = cfg['p']
-    parts = split_into_chunks(list(range(args.genes)), world)
+    # every rank gets the same total gene length (the generator's lengths are a cheap pure function of the gene id)
+    all_len = [synth.gene_length(cfg['seed'], g, cfg['l_min'], cfg['l_max']) for g in range(args.genes)] if world > 1 else None
+    parts = partition_by_length(all_len, world) if world > 1 else [list(range(args.genes))]
     my_genes = parts[rank] if rank < len(parts) else []
     t_gen = time.time()
     packed, lengths, reads, _ = synth.synth_packed(cfg['seed'], my_genes, p, cfg['l_min'], cfg['l_max'],
@@ -184,7 +186,7 @@ def main():
             'config': {'workload': 'config 2: {0} synthetic genes x {1} samples, L~U[{2},{3}], {4} DegNorm iters, '
                                    'nmf_iter {5}, fp32 coverage in HBM, fp64 arithmetic'
                                    .format(args.genes, p, cfg['l_min'], cfg['l_max'], args.iters, args.nmf_iter),
-                       'genes_per_gpu': len(my_genes), 'sharding': 'contiguous gene chunks, 1 all-reduce of 3p+1 f64 per outer iter'},
+                       'genes_per_gpu': len(my_genes), 'sharding': 'length-balanced gene partition, 1 all-reduce of 3p+1 f64 per outer iter'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
                          'traffic': traffic,

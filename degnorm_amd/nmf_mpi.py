@@ -28,7 +28,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from .utils import split_into_chunks
+from .utils import split_into_chunks, partition_by_length
 from .results import write_results
 
 __all__ = ['run_gene_nmfoa_mpi', 'save_results', 'ShardedNMFOA', 'TorchComm', 'LocalComm']
@@ -247,11 +247,13 @@ class ShardedNMFOA(object):
 # ----------------------------------------------------------------------------------------------- #
 def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate=1, min_high_coverage=50,
                        nmf_iter=100, bins=20, n_jobs=1, skip_baseline_selection=False, random_state=123,
-                       device=None, dev=None):
+                       device=None, dev=None, partition='balanced'):
     """
     Gene-sharded DegNorm run with the reference's signature (nmf_mpi.py:555-580).  Rank 0 holds
-    ``cov_dat`` (OrderedDict gene -> p x L) and ``reads_dat`` (n x p) and ships each worker its contiguous
-    chunk once (nmf_mpi.py:603-629); every rank then keeps its genes on its own GPU.
+    ``cov_dat`` (OrderedDict gene -> p x L) and ``reads_dat`` (n x p) and ships each worker its share once
+    (nmf_mpi.py:603-629); every rank then keeps its genes on its own GPU.  ``partition`` (extra): 'balanced' deals the
+    genes by length so that every GPU gets the same total length (utils.partition_by_length), 'contiguous' is the
+    reference's equal-count chunking (nmf_mpi.py:605); the results are the same, in the original gene order.
     Returns, on rank 0, {'estimates': {gene: p x L}, 'rho', 'x_adj', 'ran_baseline_selection'} in the
     original gene order (nmf_mpi.py:852-860), None elsewhere.
     """
@@ -267,7 +269,12 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
         li_vec = np.array([z.shape[1] for z in cov_dat.values()])
         if abs(int(downsample_rate)) > 1 and not np.min(li_vec) >= abs(int(downsample_rate)):
             raise ValueError('downsample_rate is too large; take-every size > at least one gene.')
-        parts = split_into_chunks(list(range(n_genes)), size)        # nmf_mpi.py:605
+        if partition == 'contiguous':
+            parts = split_into_chunks(list(range(n_genes)), size)    # nmf_mpi.py:605
+        elif partition == 'balanced':
+            parts = partition_by_length(li_vec, size)
+        else:
+            raise ValueError("partition must be 'balanced' or 'contiguous'")
         while len(parts) < size:                                      # fewer chunks than ranks: idle ranks get nothing
             parts.append([])
         for r in range(1, size):
@@ -291,14 +298,18 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
     comm.Barrier()
     if rank != 0:
         return None
-    estimates = OrderedDict()
+    by_name = dict()
     for genes_r, est_r, _, _, _ in pieces:
-        for gname, e in zip(genes_r, est_r):
-            estimates[gname] = e
-    return {'estimates': estimates,
-            'rho': np.vstack([pc[2] for pc in pieces]),
-            'x_adj': np.vstack([pc[3] for pc in pieces]),
-            'ran_baseline_selection': np.vstack([pc[4] for pc in pieces])}
+        by_name.update(zip(genes_r, est_r))
+    estimates = OrderedDict((g, by_name[g]) for g in all_genes)       # original gene order (nmf_mpi.py:852-860)
+
+    def rows(k):
+        first = pieces[0][k]
+        out = np.empty((n_genes,) + first.shape[1:], dtype=first.dtype)
+        for r, pc in enumerate(pieces):
+            out[parts[r]] = pc[k]
+        return out
+    return {'estimates': estimates, 'rho': rows(2), 'x_adj': rows(3), 'ran_baseline_selection': rows(4)}
 
 
 def save_results(genes_df, estimates, rho, x_adj, ran_baseline_selection, sample_ids=None, output_dir='.'):

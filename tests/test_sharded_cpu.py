@@ -98,7 +98,9 @@ class _ThreadComm(object):
         return View()
 
 
-def test_three_ranks_send_recv_communicator(oracle):
+@pytest.mark.parametrize('partition', ['balanced', 'contiguous'])
+def test_three_ranks_send_recv_communicator(oracle, partition):
+    """Both gene partitions (length-balanced, and the reference's contiguous chunks) give the reference's MPI result."""
     from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi
     from _oracle_device import OracleDevice
     G, cov_dat = _inputs()
@@ -107,7 +109,8 @@ def test_three_ranks_send_recv_communicator(oracle):
 
     def work(r):
         out[r] = run_gene_nmfoa_mpi(comm.view(r), cov_dat if r == 0 else None, G['reads'] if r == 0 else None,
-                                    degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), dev=OracleDevice())
+                                    degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), dev=OracleDevice(),
+                                    partition=partition)
     ths = [threading.Thread(target=work, args=(r,)) for r in range(3)]
     [t.start() for t in ths]
     [t.join() for t in ths]
@@ -115,6 +118,20 @@ def test_three_ranks_send_recv_communicator(oracle):
     np.testing.assert_allclose(out[0]['rho'], G['mpi3_rho'], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(out[0]['x_adj'], G['mpi3_x_adj'], rtol=1e-9)
     np.testing.assert_array_equal(out[0]['ran_baseline_selection'], G['mpi3_flags'])
+    assert list(out[0]['estimates'].keys()) == list(cov_dat.keys())
+
+
+def test_partition_by_length_is_balanced_and_complete():
+    from degnorm_amd.utils import partition_by_length
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(200, 5001, size=1001)
+    parts = partition_by_length(lengths, 8)
+    assert sorted(g for q in parts for g in q) == list(range(1001))
+    assert all(q == sorted(q) for q in parts)
+    assert max(len(q) for q in parts) - min(len(q) for q in parts) <= 1
+    tot = np.array([lengths[q].sum() for q in parts], dtype=np.float64)
+    assert tot.max() / tot.mean() < 1.01
+    assert [len(q) for q in partition_by_length([5, 9], 4)] == [1, 1, 0, 0]
 
 
 def test_single_rank_sharded_equals_single_node(oracle):
