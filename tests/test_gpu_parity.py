@@ -308,3 +308,47 @@ def test_one_very_long_gene_vs_oracle(device, oracle):
     np.testing.assert_allclose(rho, rho_o, rtol=1e-8, atol=1e-10)
     est = device.fetch_estimates_subset([0])
     np.testing.assert_allclose(est[0], est_o[0], rtol=1e-8, atol=1e-8)
+
+
+def test_eigen_solver_hard_spectra_vs_oracle(device, oracle):
+    """
+    Gram matrices the on-chip eigen-solver (MFMA squaring, csrc/dn_kernels.hpp top_eig_mfma) finds hard or unusual:
+    two sample groups with nearly equal energy on disjoint halves of the transcript (sigma_2 / sigma_1 close to 1, many
+    squaring steps), two identical samples (a zero eigenvalue), one dominant sample (huge dynamic range inside the
+    Gram matrix), very deep coverage (entries ~1e13) and very shallow coverage.  The oracle solves the same matrices
+    with Jacobi rotations.
+    """
+    rng = np.random.default_rng(2024)
+    p, L = 10, 1400
+    covs = []
+    # 1-3: block structure, energy ratio of the two groups 1.10, 1.03, 1.01
+    for ratio in (1.10, 1.03, 1.01):
+        mean = np.full((p, L), 2.0)
+        mean[:5, :L // 2] = 60.0
+        mean[5:, L // 2:] = 60.0 / ratio
+        covs.append(rng.poisson(mean).astype(float))
+    # 4: two identical samples
+    c = rng.poisson(np.outer(rng.lognormal(0, 0.3, p), 40 + 30 * np.sin(np.linspace(0, 6, L)) ** 2)).astype(float)
+    c[7] = c[3]
+    covs.append(c)
+    # 5: one sample 1000x deeper than the rest
+    c = rng.poisson(np.outer(np.r_[3e4, np.full(p - 1, 30.0)], 1 + np.abs(np.sin(np.linspace(0, 4, L))))).astype(float)
+    covs.append(c)
+    # 6: deep coverage everywhere (counts ~5e4, Gram entries ~4e12), 7: shallow coverage
+    covs.append(rng.poisson(np.outer(rng.uniform(3e4, 6e4, p), 0.5 + np.abs(np.sin(np.linspace(0, 5, L))))).astype(float))
+    covs.append(rng.poisson(np.outer(rng.uniform(0.5, 2.0, p), 1 + np.abs(np.sin(np.linspace(0, 5, L))))).astype(float))
+    scale = np.linspace(0.8, 1.25, p)
+    device.upload(covs)
+    assert device.inexact == 0
+    rho, flags, trace = device.baseline_iteration(scale, nmf_iter=40, want_estimates=True)
+    rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, scale, oracle.make_params(nmf_iter=40), want_estimates=True)
+    np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
+    np.testing.assert_array_equal(trace[:, 8:40], trace_o[:, 8:40])
+    np.testing.assert_array_equal(flags, flags_o)
+    # nearly degenerate top singular values make the vector itself ill-conditioned (error ~ eps / gap): 1e-7 there
+    np.testing.assert_allclose(rho[3:], rho_o[3:], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(rho[:3], rho_o[:3], rtol=1e-6, atol=1e-9)
+    est = device.fetch_estimates()
+    for k in range(3, len(covs)):
+        np.testing.assert_allclose(est[k], est_o[k], rtol=1e-7, atol=1e-7)
+    assert trace[:, 7].max() < 4000 * 41 * max(1, int(trace[:, 1].max()))       # the step cap was not what ended the solves
