@@ -27,11 +27,17 @@
 // beyond an XCD's L2 share.  The non-temporal forms (DN_SPILL_NT) were measured and did not help, and neither did a
 // column-contiguous layout with 128-bit accesses (80-B lane stride: 1.25x slower than these row-wise 8-B ones).
 #ifndef DN_SPILL_NT
-#define DN_SPILL_LOAD(p) (*(p))
-#define DN_SPILL_STORE(v, p) (*(p) = (v))
-#else
+#define DN_SPILL_NT 0            // bit 0: non-temporal loads, bit 1: non-temporal stores
+#endif
+#if DN_SPILL_NT & 1
 #define DN_SPILL_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define DN_SPILL_LOAD(p) (*(p))
+#endif
+#if DN_SPILL_NT & 2
 #define DN_SPILL_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define DN_SPILL_STORE(v, p) (*(p) = (v))
 #endif
 
 #ifndef DN_GRAM_T
