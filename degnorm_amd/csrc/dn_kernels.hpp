@@ -20,7 +20,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 #include "dn_reduce.hpp"
 
 // Spill-tier accesses: the x + lambda columns that do not fit on chip are re-read only after a whole pass, far
@@ -488,7 +487,7 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
 
 typedef DN_GRAM_T gram_t;      // per-lane Gram accumulators: double (exact mode) or float (mixed mode)
 
-template <int P, typename T, bool INIT = false>     // INIT: G = a a^T (first column of a pass: no zeroing needed)
+template <int P, typename T>
 __device__ __forceinline__ void gram_add(T (&G)[P * (P + 1) / 2], const double (&a)[P])
 {
     T b[P];
@@ -497,7 +496,7 @@ __device__ __forceinline__ void gram_add(T (&G)[P * (P + 1) / 2], const double (
 #pragma unroll
     for (int i = 0; i < P; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = INIT ? b[i] * b[j] : fma(b[i], b[j], G[i * (i + 1) / 2 + j]);
+        for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = fma(b[i], b[j], G[i * (i + 1) / 2 + j]);
 }
 
 template <int P> __device__ __forceinline__ double vmax(const double (&v)[P])
@@ -581,7 +580,7 @@ typedef double __attribute__((address_space(1))) *gdouble_ptr;
 //     lambda' = max(lambda - c (K E - x), 0)   (nmf.py:94-96)   <=>   a' = x + lambda' = max(a - c (u s - x), x),
 // with s = u . a (E_j sigma), so a pass costs 3 fp64 ops per element plus the p(p+1)/2 Gram products and
 // x + lambda is never re-formed (nmf.py:97).  lambda is not needed by itself anywhere.
-template <int P, bool INIT = false>
+template <int P>
 __device__ __forceinline__ void col_step(const double (&f)[P], double (&a)[P], const double (&u)[P], double c,
                                          gram_t (&G)[P * (P + 1) / 2])
 {
@@ -595,7 +594,7 @@ __device__ __forceinline__ void col_step(const double (&f)[P], double (&a)[P], c
         const double res = fma(u[i], s, -f[i]);                        // est - x                       nmf.py:94
         a[i] = fmax(fma(-c, res, a[i]), f[i]);                         // x + max(lambda - c res, 0)    nmf.py:95-97
     }
-    gram_add<P, gram_t, INIT>(G, a);
+    gram_add<P>(G, a);
 }
 
 template <int P>
@@ -750,10 +749,8 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
-        if constexpr (CR > 0) {
 #pragma unroll
-            for (int i = 0; i < NG; i++) G[i] = 0.0;
-        }
+        for (int i = 0; i < NG; i++) G[i] = 0.0;
         { DN_T0();
         // register tier
 #pragma unroll
@@ -765,49 +762,53 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 col_step<P>(f, lr[cc], u, c, G);
             }
         }
+        // The columns are walked forwards on even passes and backwards on odd ones (spill tier first, then the LDS tier):
+        // what the previous pass touched last -- the end of the spill state and of the counts -- is still in the XCD's
+        // L2 when the next pass starts there, where a cyclic walk over more than the L2 share never hits (+2 % on
+        // config 2, -7 % pass time for the longest genes under full load).  Keeping a separate forward-only loop for
+        // genes that fit in LDS (with the first column starting the accumulators instead of zeroing them) made every
+        // loop slower: three loop variants in one function cost more in register allocation than the zeroing does.
+        const int dir = (t & 1) ? -1 : 1;
+
         // LDS tier.  Column o keeps its p doubles contiguously (stride PS = p rounded up to even, 16-B aligned):
         // 128-bit LDS accesses, conflict-free because the lane stride (20 dwords at p = 10) is 4 x odd.
         // The next column's raw counts (10 VGPRs) are requested before this column's arithmetic starts, so the L2
         // latency of the only global read of the tier hides behind ~120 fp64 operations.  Prefetching the fp64 state
         // as well measured 1.7x SLOWER per column -- the extra live registers end up in AGPRs and every use pays a copy
         // -- and so did a register-resident tier in front of it (tools/trace_stats.py, profiles/round1).
-        // A lane's first column of the pass starts the Gram accumulators (G = a a^T) instead of zeroing 55 of them.
-        {
-            int k = NR + tid;
+        auto lds_tier = [&]() {
+            const int first = NR + tid;
+            const int cnt = first < nLe ? (nLe - first + NT - 1) / NT : 0;
+            const int step = dir * NT;
+            int k = dir > 0 ? first : first + (cnt - 1) * NT;
             float xq[P];
-            if (k < nLe) load_x<P>(Fb, k, xq);
-            auto column = [&](auto first_tag) {
-                constexpr bool FIRST = decltype(first_tag)::value;
+            if (cnt > 0) load_x<P>(Fb, k, xq);
+#pragma clang loop unroll(disable)
+            for (int j = 0; j < cnt; j++, k += step) {
                 double f[P], a[PS];
                 lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
 #pragma unroll
                 for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
-                load_x<P>(Fb, k + NT < nLe ? k + NT : k, xq);       // unconditional (clamped): no branch around the loads
+                load_x<P>(Fb, j + 1 < cnt ? k + step : k, xq);      // unconditional (clamped): no branch around the loads
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
-                col_step<P, FIRST>(f, aa, u, c, G);
+                col_step<P>(f, aa, u, c, G);
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
                 lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
-            };
-            if constexpr (CR == 0) {
-                if (k < nLe) { column(std::true_type{}); k += NT; }
-                else {
-#pragma unroll
-                    for (int i = 0; i < NG; i++) G[i] = 0.0;
-                }
             }
-#pragma clang loop unroll(disable)
-            for (; k < nLe; k += NT) column(std::false_type{});
-        }
+        };
         // spill tier: x + lambda of the columns that do not fit in LDS lives in the slot (L2 / Infinity Cache).
         // Here the loads are far away, and prefetching the next column's counts and state does pay (1.15x).
-        {
-            int k = NR + nL + tid;
+        auto spill_tier = [&]() {
+            const int first = NR + nL + tid;
+            const int cnt = first < n ? (n - first + NT - 1) / NT : 0;
+            const int step = dir * NT;
+            int k = dir > 0 ? first : first + (cnt - 1) * NT;
             float xn[P];
             double an[P];
-            if (k < n) {
+            if (cnt > 0) {
                 load_x<P>(Fb, k, xn);
                 if (t > 0) {
 #pragma unroll
@@ -815,22 +816,24 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 }
             }
 #pragma clang loop unroll(disable)
-            for (; k < n; k += NT) {
+            for (int j = 0; j < cnt; j++, k += step) {
                 double f[P], a[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) { f[i] = (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
-                if (k + NT < n) {
-                    load_x<P>(Fb, k + NT, xn);
+                if (j + 1 < cnt) {
+                    load_x<P>(Fb, k + step, xn);
                     if (t > 0) {
 #pragma unroll
-                        for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k + NT]);
+                        for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k + step]);
                     }
                 }
                 col_step<P>(f, a, u, c, G);
 #pragma unroll
                 for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], &Lg[(size_t) i * S + k]);
             }
-        }
+        };
+        if (dir > 0) { lds_tier(); spill_tier(); }
+        else { spill_tier(); lds_tier(); }
         DN_T1(0); }
         { DN_T0(); block_sum_lds<NG, P, NT, gram_t, true>(G, sm, est.mu); DN_T1(1); }       // tot = G - mu I
         { DN_T0();
