@@ -572,7 +572,7 @@ typedef double __attribute__((address_space(1))) *gdouble_ptr;
 // every pass) never leaves the chip when the gene fits: column k of lane tid = k % NT sits
 //     k <  CR*NT            in this lane's registers (lr[c][i], c = k / NT)                  "register tier"
 //     k <  CR*NT + lds_cols in the dynamic LDS tile lam[i * lds_cols + (k - CR*NT)]           "LDS tier"
-//     else                  in the slot's global spill array Lg[i * S + k]                    "HBM tier"
+//     else                  in the slot's global spill array, spill_ptr(Lg, k)[i * 64]        "spill tier"
 // On return u, theta describe the last SVD; sums[] = { sum_j s_j, clamped row sums (P), row sums of Fb (P) };
 // rs[k] = squared relative residual of column k (nmf.py:280-282), sv[k] = s_k when `first`.
 // ---------------------------------------------------------------------------------------------------
@@ -665,6 +665,16 @@ __device__ __forceinline__ void load_f(gF_cptr Fb, int k, const double (&inv)[P]
     load_x<P>(Fb, k, x);
 #pragma unroll
     for (int i = 0; i < P; i++) f[i] = (double) x[i] * inv[i];
+}
+
+// Spill-tier layout: blocks of 64 columns, inside a block the p rows of 64 doubles back to back.  A wave (64 consecutive
+// columns) reads or writes 512 contiguous bytes per row exactly as with whole rows [p][S], but the ten accesses of a
+// column differ only by the immediate offset i * 512 from ONE address -- with whole rows every row needs its own 64-bit
+// address register (20 VGPRs at p = 10), which pushed the prefetched column into AGPRs (40 extra moves per column).
+template <int P>
+__device__ __forceinline__ gdouble_ptr spill_ptr(gdouble_ptr Lg, int k)
+{
+    return Lg + ((size_t) (k >> 6) * (64 * P) + (size_t) (k & 63));
 }
 
 // Out of line on purpose: the call has its own register allocation (Gram accumulators + one column in
@@ -812,7 +822,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 load_x<P>(Fb, k, xn);
                 if (t > 0) {
 #pragma unroll
-                    for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k]);
+                    for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
                 }
             }
 #pragma clang loop unroll(disable)
@@ -824,12 +834,12 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                     load_x<P>(Fb, k + step, xn);
                     if (t > 0) {
 #pragma unroll
-                        for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k + step]);
+                        for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k + step) + i * 64);
                     }
                 }
                 col_step<P>(f, a, u, c, G);
 #pragma unroll
-                for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], &Lg[(size_t) i * S + k]);
+                for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], spill_ptr<P>(Lg, k) + i * 64);
             }
         };
         if (dir > 0) { lds_tier(); spill_tier(); }
@@ -869,7 +879,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             for (int i = 0; i < P; i++) l[i] = al[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < P; i++) l[i] = DN_SPILL_LOAD(&Lg[(size_t) i * S + k]);
+            for (int i = 0; i < P; i++) l[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
         }
         col_final<P>(f, l, u, first, acc, s, r);
         rs[k] = r;
@@ -916,7 +926,7 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
     char *slot = A.ws + (size_t) blockIdx.x * A.slot_bytes;
     float *Fs = reinterpret_cast<float *>(slot);                      // pristine compacted raw counts  [P][S]
     float *Fb = Fs + (size_t) P * S;                                  // working copy after bin drops   [S][P]
-    double *Lg = reinterpret_cast<double *>(Fb + (size_t) P * S);     // x + lambda, HBM tier           [P][S]
+    double *Lg = reinterpret_cast<double *>(Fb + (size_t) P * S);     // x + lambda, spill tier         [S / 64][P][64]
     double *sv = Lg + (size_t) P * S;                                 // s_start                        [S]
     double *rs = sv + S;                                              // residual profile               [S]
     if (tid < P) gs.inv[tid] = A.inv_scale[tid];
