@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 constexpr int P = 10, NG = 55, PS = 10;
+typedef double d4 __attribute__((ext_vector_type(4)));
 template <int MODE, int NT>   // bit0: LDS state traffic, bit1: Gram, bit2: update math
 __global__ __launch_bounds__(NT) void k(double *out, int cols_per_lane, int iters, int nthreads, const float *Fb = nullptr, int S = 0)
 {
@@ -30,6 +31,41 @@ __global__ __launch_bounds__(NT) void k(double *out, int cols_per_lane, int iter
                 for (int i = 0; i < P; i++) for (int j = 0; j <= i; j++) { double g = G[i * (i + 1) / 2 + j]; g = fma(a[i], a[j], g); g = fma(b[i], b[j], g); G[i * (i + 1) / 2 + j] = g; }
                 for (int i = 0; i < P; i += 2) { *(double2 *) (ca + i) = make_double2(a[i], a[i + 1]); *(double2 *) (cb + i) = make_double2(b[i], b[i + 1]); }
             }
+        } else if (MODE & 32) {
+            // update on the VALU; Gram of 3 steps out of 5 on the matrix core, software-pipelined: the MFMAs of step c - 1
+            // (its updated columns re-read from LDS in the operand layout: lane (i = l & 15, kq = l >> 4) <- row i of
+            // column 4 g + kq of the wave's block) sit in the same basic block as the VALU work of step c.
+            d4 acc = {0, 0, 0, 0};
+            const int l = tid & 63, wv = tid >> 6;
+            const double keep = (l & 15) < P ? 1.0 : 0.0;
+            const size_t lane_off = (size_t) ((l & 15) < P ? (l & 15) : 0) + (size_t) (l >> 4) * PS;
+            auto step = [&](int c, bool valu_gram, bool mfma_prev) {
+                double a[P], f[P];
+                double *col = lam + (size_t) (c * nthreads + tid) * PS;
+                for (int i = 0; i < P; i += 2) { double2 v = *(double2 *) (col + i); a[i] = v.x; a[i + 1] = v.y; }
+                for (int i = 0; i < P; i++) f[i] = 2.0 + i + c;
+                double s = 0; for (int i = 0; i < P; i++) s = fma(u[i], a[i], s);
+                for (int i = 0; i < P; i++) { double res = fma(u[i], s, -f[i]); a[i] = fmax(fma(-0.1, res, a[i]), f[i]); }
+                if (mfma_prev) {
+                    const double *blk = lam + (size_t) ((c - 1) * nthreads + wv * 64) * PS + lane_off;
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        const double x = blk[(size_t) g * 4 * PS] * keep;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+                    }
+                }
+                if (valu_gram) for (int i = 0; i < P; i++) for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = fma(a[i], a[j], G[i * (i + 1) / 2 + j]);
+                for (int i = 0; i < P; i += 2) *(double2 *) (col + i) = make_double2(a[i], a[i + 1]);
+            };
+#pragma clang loop unroll(disable)
+            for (int c0 = 0; c0 + 5 <= cols_per_lane; c0 += 5) {
+                step(c0, false, false);                       // steps 0,1,2 -> MFMA (issued one step later); 3,4 -> VALU
+                step(c0 + 1, false, true);
+                step(c0 + 2, false, true);
+                step(c0 + 3, true, true);
+                step(c0 + 4, true, false);
+            }
+            G[0] += acc[0] + acc[1] + acc[2] + acc[3];
         } else
 #pragma clang loop unroll(disable)
         for (int c = 0; c < cols_per_lane; c++) {
@@ -58,7 +94,7 @@ template <int MODE, int NT> void run1(const char *name, double *d)
 {
     {
         const int nthreads = NT;
-        const int total_cols = 1536, cpl = total_cols / nthreads;
+        const int total_cols = (MODE & 32) ? 1280 : 1536, cpl = total_cols / nthreads;   // the MFMA mode walks 5 columns per trip
         size_t lds = (size_t) total_cols * PS * 8;
         hipFuncSetAttribute((const void *) k<MODE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -78,6 +114,7 @@ int main()
     double *d; hipMalloc(&d, 64);
 #define RUN(M, name) run1<M, 256>(name, d); run1<M, 512>(name, d);
     RUN(7, "LDS + update + Gram")
+    run1<39, 256>("same, Gram 3/5 on MFMA", d);     // 1 536 vs 885 ticks: fp64 MFMA and fp64 VALU do not overlap
     RUN(23, "full + F from L2 (fp32, scaled)")
     RUN(15, "2-column interleave, full")
     RUN(6, "update + Gram (no LDS)")
