@@ -19,7 +19,7 @@ P_LIST = list(range(2, 13))          # keep in sync with DN_FOR_EACH_P in csrc/d
 ARCH = 'gfx950'
 WIDE_NT = int(os.environ.get('DN_WIDE_NT', 256))     # wide-class workgroup size (csrc/dn_api.hip DN_WIDE_NT)
 NT_LIST = (WIDE_NT, 128)
-EXTRA = ['-D' + d for d in os.environ.get('DN_DEFINES', '').split() if d]   # e.g. DN_DEFINES='DN_CR=2'
+EXTRA = ['-D' + d for d in os.environ.get('DN_DEFINES', '').split() if d]   # e.g. DN_DEFINES='DN_STAMP=1'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on',
          '-Wall', '-Wno-unused-function']
 

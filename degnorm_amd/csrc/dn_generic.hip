@@ -530,7 +530,7 @@ const KernelSet *kernel_set_generic()
 {
     static const KernelSet ks = {
         0, gen::NT, gen::launch_baseline, gen::launch_init, gen::launch_est, gen::blocks_per_cu,
-        0, (size_t) 160 * 1024,            // no LDS tier: "static" covers the CU so that lds_cols comes out 0
+        (size_t) 160 * 1024,               // no LDS tier: "static" covers the CU so that lds_cols comes out 0
         "k_baseline_gen",
     };
     return &ks;

@@ -15,22 +15,18 @@
 #define DN_STR_(a) #a
 #define DN_STR(a) DN_STR_(a)
 
-#ifndef DN_CR
-#define DN_CR 0        // register-resident tier: measured slower than the LDS tier, kept for experiments
-#endif
-
 namespace dn {
 
 static int launch_baseline(const IterArgs &a, int grid, size_t dyn_lds, hipStream_t s)
 {
     static size_t configured = 0;
     if (dyn_lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_baseline<DN_P, DN_NT, DN_CR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_baseline<DN_P, DN_NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn_lds);
         if (e != hipSuccess) return (int) e;
         configured = dyn_lds;
     }
-    hipLaunchKernelGGL((k_baseline<DN_P, DN_NT, DN_CR>), dim3(grid), dim3(DN_NT), dyn_lds, s, a);
+    hipLaunchKernelGGL((k_baseline<DN_P, DN_NT>), dim3(grid), dim3(DN_NT), dyn_lds, s, a);
     return (int) hipGetLastError();
 }
 
@@ -48,7 +44,7 @@ static int blocks_per_cu(int which)
 {
     int nb = 0;
     hipError_t e;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline<DN_P, DN_NT, DN_CR>, DN_NT, 0);
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline<DN_P, DN_NT>, DN_NT, 0);
     else            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd<DN_P, DN_NT>, DN_NT, 0);
     return e == hipSuccess ? nb : 0;
 }
@@ -57,10 +53,10 @@ static int blocks_per_cu(int which)
 const KernelSet *DN_CAT3(kernel_set_p, DN_P, _nt, DN_NT)()
 {
     static char name[64];
-    snprintf(name, sizeof(name), "k_baseline<%d,%d,%d>", (int) DN_P, (int) DN_NT, (int) (DN_CR));
+    snprintf(name, sizeof(name), "k_baseline<%d,%d>", (int) DN_P, (int) DN_NT);
     static const KernelSet ks = {
         DN_P, DN_NT, launch_baseline, launch_init, launch_est, blocks_per_cu,
-        DN_CR, sizeof(Smem<DN_P, DN_NT>) + sizeof(GeneState<DN_P>),
+        sizeof(Smem<DN_P, DN_NT>) + sizeof(GeneState<DN_P>),
         name,
     };
     return &ks;

@@ -566,13 +566,13 @@ typedef double __attribute__((address_space(1))) *gdouble_ptr;
 // ---------------------------------------------------------------------------------------------------
 // One nmf() call on the compacted working matrix (p x n) -- nmf.py:78-107.
 //
-// Where the data lives.  Fb: the raw fp32 counts of the n active columns (row stride S) in the workgroup's
-// scratch slot -- read-only inside the call, ~40 B per column per pass, served by the XCD's L2 because the
-// slot is touched by this CU only.  F = x * (1/s_i) is formed in registers.  lambda (fp64, read AND written
-// every pass) never leaves the chip when the gene fits: column k of lane tid = k % NT sits
-//     k <  CR*NT            in this lane's registers (lr[c][i], c = k / NT)                  "register tier"
-//     k <  CR*NT + lds_cols in the dynamic LDS tile lam[i * lds_cols + (k - CR*NT)]           "LDS tier"
+// Where the data lives.  Fb: the raw fp32 counts of the n active columns (column-contiguous, p floats per column) in
+// the workgroup's scratch slot -- read-only inside the call, ~40 B per column per pass, served by the XCD's L2 /
+// Infinity Cache because the slot is touched by this CU only.  F = x * (1/s_i) is formed in registers.  The state
+// (fp64, read AND written every pass) never leaves the chip when the gene fits: column k of lane tid = k % NT sits
+//     k <  lds_cols         in the dynamic LDS tile lam[k * PS + i]                           "LDS tier"
 //     else                  in the slot's global spill array, spill_ptr(Lg, k)[i * 64]        "spill tier"
+// (a register-resident tier in front of these was measured slower and is gone: DESIGN.md, dead ends)
 // On return u, theta describe the last SVD; sums[] = { sum_j s_j, clamped row sums (P), row sums of Fb (P) };
 // rs[k] = squared relative residual of column k (nmf.py:280-282), sv[k] = s_k when `first`.
 // ---------------------------------------------------------------------------------------------------
@@ -679,7 +679,7 @@ __device__ __forceinline__ gdouble_ptr spill_ptr(gdouble_ptr Lg, int k)
 
 // Out of line on purpose: the call has its own register allocation (Gram accumulators + one column in
 // flight), independent of what the state machine keeps live, so that two waves fit on a SIMD.
-template <int P, int NT, int CR>
+template <int P, int NT>
 __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_, double *rs_, double *sv_,
                                                    int n, int S, int nL, int T, int first_i)
 {
@@ -709,12 +709,10 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #define DN_T1(slot) (void) stamp
 #endif
     constexpr int NG = P * (P + 1) / 2;
-    constexpr int NR = CR * NT;
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
     const int tid = threadIdx.x;
-    const int nLe = (n < NR + nL) ? n : NR + nL;          // end of the LDS tier
+    const int nLe = (n < nL) ? n : nL;                     // end of the LDS tier
     gram_t G[NG];
-    double lr[CR > 0 ? CR : 1][P];
 
     // cold start: SVD of x itself (nmf.py:88)
 #pragma unroll
@@ -743,18 +741,12 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma unroll
     for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
 
-#pragma unroll
-    for (int cc = 0; cc < CR; cc++) {                                  // lmbda = zeros (nmf.py:90): a = x
-        const int k = cc * NT + tid;
-        if (k < n) load_f<P>(Fb, k, inv, lr[cc]);
-    }
-
-    for (int k = NR + tid; k < nLe; k += NT) {                       // lmbda = zeros (nmf.py:90): state a = x
+    for (int k = tid; k < nLe; k += NT) {                       // lmbda = zeros (nmf.py:90): state a = x
         double f[P], a[PS];
         load_f<P>(Fb, k, inv, f);
 #pragma unroll
         for (int i = 0; i < PS; i++) a[i] = i < P ? f[i] : 0.0;
-        lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
+        lds_col_write<PS>(lam + (size_t) k * PS, a);
     }
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
 #pragma clang loop unroll(disable)
@@ -762,16 +754,6 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma unroll
         for (int i = 0; i < NG; i++) G[i] = 0.0;
         { DN_T0();
-        // register tier
-#pragma unroll
-        for (int cc = 0; cc < CR; cc++) {
-            const int k = cc * NT + tid;
-            if (k < n) {
-                double f[P];
-                load_f<P>(Fb, k, inv, f);
-                col_step<P>(f, lr[cc], u, c, G);
-            }
-        }
         // The columns are walked forwards on even passes and backwards on odd ones (spill tier first, then the LDS tier):
         // what the previous pass touched last -- the end of the spill state and of the counts -- is still in the XCD's
         // L2 when the next pass starts there, where a cyclic walk over more than the L2 share never hits (+2 % on
@@ -787,7 +769,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         // as well measured 1.7x SLOWER per column -- the extra live registers end up in AGPRs and every use pays a copy
         // -- and so did a register-resident tier in front of it (tools/trace_stats.py, profiles/round1).
         auto lds_tier = [&]() {
-            const int first = NR + tid;
+            const int first = tid;
             const int cnt = first < nLe ? (nLe - first + NT - 1) / NT : 0;
             const int step = dir * NT;
             int k = dir > 0 ? first : first + (cnt - 1) * NT;
@@ -796,7 +778,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma clang loop unroll(disable)
             for (int j = 0; j < cnt; j++, k += step) {
                 double f[P], a[PS];
-                lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
+                lds_col_read<PS>(lam + (size_t) k * PS, a);
 #pragma unroll
                 for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
                 load_x<P>(Fb, j + 1 < cnt ? k + step : k, xq);      // unconditional (clamped): no branch around the loads
@@ -806,13 +788,13 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 col_step<P>(f, aa, u, c, G);
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
-                lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
+                lds_col_write<PS>(lam + (size_t) k * PS, a);
             }
         };
         // spill tier: x + lambda of the columns that do not fit in LDS lives in the slot (L2 / Infinity Cache).
         // Here the loads are far away, and prefetching the next column's counts and state does pay (1.15x).
         auto spill_tier = [&]() {
-            const int first = NR + nL + tid;
+            const int first = nL + tid;
             const int cnt = first < n ? (n - first + NT - 1) / NT : 0;
             const int step = dir * NT;
             int k = dir > 0 ? first : first + (cnt - 1) * NT;
@@ -857,24 +839,13 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     double acc[2 * P + 1];
 #pragma unroll
     for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
-#pragma unroll
-    for (int cc = 0; cc < CR; cc++) {
-        const int k = cc * NT + tid;
-        if (k < n) {
-            double f[P], s, r;
-            load_f<P>(Fb, k, inv, f);
-            col_final<P>(f, lr[cc], u, first, acc, s, r);
-            rs[k] = r;
-            if (first) sv[k] = s;
-        }
-    }
 #pragma clang loop unroll(disable)
-    for (int k = NR + tid; k < n; k += NT) {
+    for (int k = tid; k < n; k += NT) {
         double f[P], l[P], s, r;
         load_f<P>(Fb, k, inv, f);
         if (k < nLe) {
             double al[PS];
-            lds_col_read<PS>(lam + (size_t) (k - NR) * PS, al);
+            lds_col_read<PS>(lam + (size_t) k * PS, al);
 #pragma unroll
             for (int i = 0; i < P; i++) l[i] = al[i];
         } else {
@@ -902,7 +873,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 
 // ---------------------------------------------------------------------------------------------------
 // k_baseline: the per-gene state machine.  Gene-level vectors (rho, K, ...) are wave-uniform and live in
-// LDS (GeneState) so that the registers belong to the Gram accumulators and the lambda register tier.
+// LDS (GeneState) so that the registers belong to the Gram accumulators and the column in flight.
 // ---------------------------------------------------------------------------------------------------
 
 template <int P> __device__ __forceinline__ double lds_max(const double *v)
@@ -914,7 +885,7 @@ template <int P> __device__ __forceinline__ double lds_min(const double *v)
 #pragma unroll
   for (int i = 1; i < P; i++) { const double t = v[i]; m = t < m ? t : m; } return m; }
 
-template <int P, int NT, int CR>
+template <int P, int NT>
 __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
 {
     constexpr int W = NT / 64;
@@ -1043,7 +1014,7 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
                 // One nmf() call per trip: the first on F_start (nmf.py:245), the others inside the
                 // `while max(rho) > 0.1` loop of nmf.py:273-324 after a bin has been dropped.
                 for (;;) {
-                    nmf_call<P, NT, CR>(Fb, Lg, rs, sv, n, S, nL, A.T, first ? 1 : 0);       // results in gs (LDS)
+                    nmf_call<P, NT>(Fb, Lg, rs, sv, n, S, nL, A.T, first ? 1 : 0);       // results in gs (LDS)
                     if (gs.status != ST_OK) { status = gs.status; break; }
                     const double *u = gs.u, *sums = gs.sums;
                     const double theta = gs.theta;
@@ -1348,7 +1319,6 @@ struct KernelSet {
     init_launch_fn init;
     est_launch_fn est;
     occupancy_fn blocks_per_cu;       // which: 0 baseline (no dynamic LDS), 1 init
-    int cr;                           // lambda columns per lane held in registers
     size_t static_lds_bytes;          // static LDS of k_baseline
     const char *baseline_name;
 };

@@ -29,7 +29,7 @@ def write_summary(per, out):
 
 
 def spaced(name):
-    """k_baseline<10,256,0> -> k_baseline<10, 256, 0> (how rocprofv3 prints template arguments)."""
+    """k_baseline<10,256> -> k_baseline<10, 256> (how rocprofv3 prints template arguments)."""
     inner = name[name.index('<') + 1:-1].split(',')
     return name[:name.index('<') + 1] + ', '.join(inner) + '>'
 
@@ -56,7 +56,7 @@ def main():
     shutil.copy(os.path.join(src, 'bench.json'), os.path.join(dst, prefix + 'bench.json'))
 
     bench = json.load(open(os.path.join(src, 'bench.json')))
-    name = bench['roofline']['kernel']                               # e.g. k_baseline<10,256,0>
+    name = bench['roofline']['kernel']                               # e.g. k_baseline<10,256>
     wide = spaced(name)
     narrow_name = bench['roofline'].get('second_kernel', {}).get('kernel', '')
     f_w, w_w = mean_of(fetch, wide), mean_of(write, wide)
