@@ -1,8 +1,11 @@
-set -e
-cp degnorm_amd/libdegnorm_amd.so /tmp/lib_keep.so
-for v in nt2 nt1; do
-  cp build_variants/lib_$v.so degnorm_amd/libdegnorm_amd.so
-  echo "variant $v: genes 1024 L 5000"; timeout -k 10 200 python tools/trace_stats.py 1024 100 5000 2>&1 | grep -E "launch ms|per inner iteration:|pass cycles" | tail -3
-  echo "variant $v mixed"; timeout -k 10 200 python tools/trace_stats.py 4000 100 2>&1 | grep -E "launch ms" | tail -1
+#!/bin/bash
+# How much the pass of a long gene slows down when the whole chip runs long genes ("The memory side
+# matters after all").  Needs the diagnostic build: DN_DEFINES=DN_STAMP=1 python -m degnorm_amd.build --force
+for n in 8 64 256 1024; do
+  echo "genes $n, L 5000"
+  timeout -k 10 200 python tools/trace_stats.py $n 100 5000 2>&1 | grep -E "per inner iteration:|pass cycles"
 done
-cp /tmp/lib_keep.so degnorm_amd/libdegnorm_amd.so
+for n in 8 256; do
+  echo "genes $n, L 1800"
+  timeout -k 10 200 python tools/trace_stats.py $n 100 1800 2>&1 | grep -E "per inner iteration:|pass cycles"
+done

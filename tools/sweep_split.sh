@@ -1,1 +1,5 @@
-for s in 1600 2047 2400 2800; do echo "split $s"; DN_SPLIT_LEN=$s timeout -k 10 200 python tools/trace_stats.py 4000 100 2>&1 | grep -E "launch ms" | tail -1; done
+#!/bin/bash
+# Sweep of the narrow / wide class boundary (DN_SPLIT_LEN overrides the 2.1 x LDS-columns default of dn_api.hip).
+for s in "$@"; do
+  DN_SPLIT_LEN=$s python bench.py --cpu-sample 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('split $s', round(d['value'],1), 'genes/s', round(d['ms_per_step'],1), 'ms/step', round(d['roofline']['avg_launch_ms'],1), round(d['roofline']['second_kernel']['launch_to_end_ms'],1))"
+done

@@ -1,4 +1,6 @@
-# A/B of prebuilt library variants under build_variants/ (experiment helper): bash tools/variant_ab.sh base nt2 base nt2
+#!/bin/bash
+# A/B of prebuilt library variants (experiment helper): build each variant with `python -m degnorm_amd.build --force`,
+# copy degnorm_amd/libdegnorm_amd.so to build_variants/lib_<name>.so, then: bash tools/variant_ab.sh base new base new
 cp degnorm_amd/libdegnorm_amd.so /tmp/lib_keep.so
 for v in "$@"; do
   cp build_variants/lib_$v.so degnorm_amd/libdegnorm_amd.so
