@@ -108,7 +108,6 @@ struct dn_handle_s {
         const dn::KernelSet *ks = nullptr;
         int32_t n = 0;
         int32_t *d_order = nullptr;
-        std::vector<int32_t> order;       // host copy of the work queue (gene ids)
         int32_t *d_counter = nullptr;
         char *d_ws = nullptr;
         int slots = 0;
@@ -128,9 +127,7 @@ struct dn_handle_s {
     double last_scale[dn::P_MAX] = {0};
     bool have_estimate_state = false;
     float last_ms = 0.f;
-    // per-gene counters of the previous dn_baseline_iteration: the next one orders its queues by the work they predict
-    std::vector<int32_t> host_trace;
-    bool have_trace = false;
+
 };
 
 static void free_device(dn_handle h)
@@ -214,7 +211,6 @@ static int finish_upload(dn_handle h, const float *host_packed)
     HIP_TRY(hipSetDevice(h->device));
 
     // work queue: longest gene first (a 17-call gene costs ~17x a 1-call gene)
-    h->have_trace = false;
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return h->glen[a] > h->glen[b]; });
@@ -277,7 +273,9 @@ static int finish_upload(dn_handle h, const float *host_packed)
             // Long genes keep most of their state in the spill tier and pull ~60 GB/s per CU through the fabric, short
             // ones a quarter of that; running only long genes everywhere at the start of a launch saturates the fabric
             // (their pass is 1.4x slower than alone on the chip, tools/contention.sh).  The zigzag keeps the demand level
-            // over the launch: +2.9 % on config 2.  DN_ORDER_MIX=0 restores plain longest-first, bit c selects class c.
+            // over the launch: +2.9 % on config 2 and more on short queues (+6 % at 5 000 genes per GPU against ordering
+            // by the cost predicted from the previous iteration's counters, which clusters the heavy genes even more).
+            // DN_ORDER_MIX=0 restores plain longest-first, bit c selects class c.
             const char *mix = getenv("DN_ORDER_MIX");
             const int mask = mix ? atoi(mix) : 1;
             for (int c = 0; c < 2; c++) {
@@ -297,7 +295,6 @@ static int finish_upload(dn_handle h, const float *host_packed)
             HIP_TRY(hipMalloc(&C.d_order, sizeof(int32_t) * (size_t) C.n));
             HIP_TRY(hipMalloc(&C.d_counter, sizeof(int32_t) * 4));
             HIP_TRY(hipMemcpy(C.d_order, ord[c].data(), sizeof(int32_t) * (size_t) C.n, hipMemcpyHostToDevice));
-            C.order = ord[c];
             int per_cu = C.ks->blocks_per_cu(0);
             if (per_cu < 1) per_cu = 1;
             C.slots = (int) std::min<int64_t>(C.n, (int64_t) per_cu * h->n_cus);
@@ -461,28 +458,6 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
         HIP_TRY(hipMemcpyAsync(h->d_ds, ds_start, sizeof(int64_t) * (size_t) h->n, hipMemcpyHostToDevice, h->stream));
         a.ds_start = h->d_ds;
     }
-    // Work queues: longest gene first on the first iteration; afterwards, for SHORT queues, most expensive first, where
-    // the cost of a gene is predicted from the previous iteration's counters (sum of active columns over its nmf()
-    // calls plus a fixed part per call worth ~4 columns per lane).  The number of calls varies 0..17 between genes of
-    // one length, so this shortens the tail of a launch: +2.3 % at 2 500 genes per GPU.  Long queues (>= 16 genes per
-    // workgroup) keep the length order: there the tail is negligible and length order spreads the spill-heavy genes
-    // over the launch, which the fabric likes better (-3 % with the work order at 20 000 genes).  Results do not depend
-    // on the order.
-    if (h->have_trace && getenv("DN_STATIC_ORDER") == nullptr) {
-        for (auto &C : h->cls) {
-            if (C.n == 0 || !C.ks || C.n >= 16 * std::max(C.slots, 1)) continue;
-            const double per_call = 4.0 * (double) (C.ks->nt > 0 ? C.ks->nt : 256);
-            std::vector<std::pair<double, int32_t>> key((size_t) C.n);
-            for (int32_t k = 0; k < C.n; k++) {
-                const int32_t g = C.order[k];
-                const int32_t *tr = &h->host_trace[(size_t) g * dn::TRACE_LEN];
-                key[k] = {(double) tr[2] + per_call * (double) tr[1] + 1e-3 * (double) h->glen[g], g};
-            }
-            std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
-            for (int32_t k = 0; k < C.n; k++) C.order[k] = key[k].second;
-            HIP_TRY(hipMemcpyAsync(C.d_order, C.order.data(), sizeof(int32_t) * (size_t) C.n, hipMemcpyHostToDevice, h->stream));
-        }
-    }
     HIP_TRY(hipMemsetAsync(h->d_trace, 0, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, h->stream));
     for (auto &C : h->cls) if (C.n > 0) HIP_TRY(hipMemsetAsync(C.d_counter, 0, sizeof(int32_t) * 4, h->stream));
     HIP_TRY(hipEventRecord(h->ev_ready, h->stream));
@@ -502,11 +477,9 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     if (h->cls[1].n > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev2b, 0));     // results are copied on the main stream
     HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
-    h->host_trace.resize((size_t) h->n * dn::TRACE_LEN);
-    HIP_TRY(hipMemcpyAsync(h->host_trace.data(), h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
+    if (trace)
+        HIP_TRY(hipMemcpyAsync(trace, h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->have_trace = (prm->downsample_rate <= 1);          // with down-sampling the active columns are redrawn every iteration
-    if (trace) std::memcpy(trace, h->host_trace.data(), sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN);
     if (h->cls[0].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[0].last_ms, h->ev0, h->ev1));
     if (h->cls[1].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[1].last_ms, h->ev2a, h->ev2b));
     h->last_ms = h->cls[0].n > 0 ? h->cls[0].last_ms : h->cls[1].last_ms;
