@@ -108,6 +108,7 @@ struct dn_handle_s {
         const dn::KernelSet *ks = nullptr;
         int32_t n = 0;
         int32_t *d_order = nullptr;
+        std::vector<int32_t> order;       // host copy of the work queue (gene ids)
         int32_t *d_counter = nullptr;
         char *d_ws = nullptr;
         int slots = 0;
@@ -127,6 +128,9 @@ struct dn_handle_s {
     double last_scale[dn::P_MAX] = {0};
     bool have_estimate_state = false;
     float last_ms = 0.f;
+    // per-gene counters of the previous dn_baseline_iteration: the narrow class orders its queue by the work they predict
+    std::vector<int32_t> host_trace;
+    bool have_trace = false;
 
 };
 
@@ -211,6 +215,7 @@ static int finish_upload(dn_handle h, const float *host_packed)
     HIP_TRY(hipSetDevice(h->device));
 
     // work queue: longest gene first (a 17-call gene costs ~17x a 1-call gene)
+    h->have_trace = false;
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return h->glen[a] > h->glen[b]; });
@@ -295,6 +300,7 @@ static int finish_upload(dn_handle h, const float *host_packed)
             HIP_TRY(hipMalloc(&C.d_order, sizeof(int32_t) * (size_t) C.n));
             HIP_TRY(hipMalloc(&C.d_counter, sizeof(int32_t) * 4));
             HIP_TRY(hipMemcpy(C.d_order, ord[c].data(), sizeof(int32_t) * (size_t) C.n, hipMemcpyHostToDevice));
+            C.order = ord[c];
             int per_cu = C.ks->blocks_per_cu(0);
             if (per_cu < 1) per_cu = 1;
             C.slots = (int) std::min<int64_t>(C.n, (int64_t) per_cu * h->n_cus);
@@ -458,6 +464,26 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
         HIP_TRY(hipMemcpyAsync(h->d_ds, ds_start, sizeof(int64_t) * (size_t) h->n, hipMemcpyHostToDevice, h->stream));
         a.ds_start = h->d_ds;
     }
+    // The narrow class (state in LDS, little fabric traffic) orders its queue most expensive first from the second
+    // iteration on, the cost of a gene predicted from the previous iteration's counters (sum of active columns over its
+    // nmf() calls plus a fixed part per call worth ~4 columns per lane): its genes are what fills the end of a launch.
+    // The wide class keeps the zigzag (it is bound by the fabric, see upload).  DN_NARROW_WORK_ORDER=0 disables.
+    {
+        const char *wo = getenv("DN_NARROW_WORK_ORDER");
+        auto &C = h->cls[1];
+        if (h->have_trace && C.n > 0 && C.ks && !(wo && wo[0] == '0')) {
+            const double per_call = 4.0 * (double) (C.ks->nt > 0 ? C.ks->nt : 128);
+            std::vector<std::pair<double, int32_t>> key((size_t) C.n);
+            for (int32_t k = 0; k < C.n; k++) {
+                const int32_t g = C.order[k];
+                const int32_t *tr = &h->host_trace[(size_t) g * dn::TRACE_LEN];
+                key[k] = {(double) tr[2] + per_call * (double) tr[1] + 1e-3 * (double) h->glen[g], g};
+            }
+            std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
+            for (int32_t k = 0; k < C.n; k++) C.order[k] = key[k].second;
+            HIP_TRY(hipMemcpyAsync(C.d_order, C.order.data(), sizeof(int32_t) * (size_t) C.n, hipMemcpyHostToDevice, h->stream));
+        }
+    }
     HIP_TRY(hipMemsetAsync(h->d_trace, 0, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, h->stream));
     for (auto &C : h->cls) if (C.n > 0) HIP_TRY(hipMemsetAsync(C.d_counter, 0, sizeof(int32_t) * 4, h->stream));
     HIP_TRY(hipEventRecord(h->ev_ready, h->stream));
@@ -477,9 +503,11 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     if (h->cls[1].n > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev2b, 0));     // results are copied on the main stream
     HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
-    if (trace)
-        HIP_TRY(hipMemcpyAsync(trace, h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
+    h->host_trace.resize((size_t) h->n * dn::TRACE_LEN);
+    HIP_TRY(hipMemcpyAsync(h->host_trace.data(), h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_trace = (prm->downsample_rate <= 1);          // with down-sampling the active columns are redrawn every iteration
+    if (trace) std::memcpy(trace, h->host_trace.data(), sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN);
     if (h->cls[0].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[0].last_ms, h->ev0, h->ev1));
     if (h->cls[1].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[1].last_ms, h->ev2a, h->ev2b));
     h->last_ms = h->cls[0].n > 0 ? h->cls[0].last_ms : h->cls[1].last_ms;
