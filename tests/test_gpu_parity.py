@@ -352,3 +352,34 @@ def test_eigen_solver_hard_spectra_vs_oracle(device, oracle):
     for k in range(3, len(covs)):
         np.testing.assert_allclose(est[k], est_o[k], rtol=1e-7, atol=1e-7)
     assert trace[:, 7].max() < 4000 * 41 * max(1, int(trace[:, 1].max()))       # the step cap was not what ended the solves
+
+
+@pytest.mark.parametrize('p', [5, 10])
+def test_many_small_ragged_genes_vs_oracle(device, oracle, p):
+    """
+    300 genes of every small length (2 .. 420 bases, around the 64 / 128 / 256 lane and wave boundaries) with three
+    depth regimes: the column loops run 0, 1 or 2 trips per lane in either direction, passes with an empty LDS or spill
+    tier, workgroups that finish a gene before the others start one.
+    """
+    rng = np.random.default_rng(31 + p)
+    covs = []
+    for k in range(300):
+        L = int(rng.integers(2, 421))
+        depth = (0.5, 30.0, 3000.0)[k % 3]
+        env = 1.0 + np.abs(np.sin(np.linspace(0, rng.uniform(1, 6), L)))
+        mean = depth * np.outer(rng.lognormal(0, 0.4, p), env)
+        if k % 7 == 0:
+            mean[rng.integers(0, p), : max(1, L // 3)] *= 0.3        # a degraded stretch in one sample
+        covs.append(rng.poisson(mean).astype(float))
+    scale = np.linspace(0.85, 1.15, p)
+    device.upload(covs)
+    for T, mhc in ((7, 50), (4, 2)):
+        rho, flags, trace = device.baseline_iteration(scale, nmf_iter=T, min_high_coverage=mhc, want_estimates=True)
+        prm = oracle.make_params(nmf_iter=T, min_high_coverage=mhc)
+        rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, scale, prm, want_estimates=True)
+        np.testing.assert_array_equal(trace[:, [0, 1, 2, 3, 5, 6]], trace_o[:, [0, 1, 2, 3, 5, 6]])
+        np.testing.assert_array_equal(flags, flags_o)
+        np.testing.assert_allclose(rho, rho_o, rtol=1e-8, atol=1e-10)
+        est = device.fetch_estimates()
+        for a, b in zip(est, est_o):
+            np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8)
