@@ -922,7 +922,9 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
         int n0 = 0, n_calls = 0, n_drops = 0, exit_code = EXIT_LOW_COV, loop_reason = LOOP_NOT_ENTERED;
         int status = ST_OK, flag = 0, emode = EM_INPUT;
         long long sum_cols = 0;
+#ifdef DN_STAMP
         const long long t_gene0 = __builtin_amdgcn_s_memtime();
+#endif
         int32_t *tr = A.trace + (size_t) g * TRACE_LEN;
         if (tid < P) { gs.rho[tid] = 0.0; gs.K[tid] = 0.0; gs.us[tid] = 0.0; }
         if (tid == 0) { gs.steps = 0; gs.stamp[0] = gs.stamp[1] = gs.stamp[2] = 0; }
