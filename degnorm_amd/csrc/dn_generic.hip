@@ -7,7 +7,9 @@
 // reduction), with the x + lambda state in the workgroup's scratch slot (L2-resident).  For p > 24 this is also
 // cheaper than forming the Gram (2 p n per step against p^2 n / 2).  When n < p (the down-sampled regime) the
 // same iteration converges to the same top singular triplet; scipy switches to the n x n Gram there, the result
-// is the identical rank-1 factor.  This path is about coverage of the interface, not about speed.
+// is the identical rank-1 factor -- and so does nmf_rows below, which serves active matrices of at most 12 columns
+// (all of config 4) from registers, one wave per gene, with the machinery of the templated kernels.  The block-wide
+// path (nmf_gen) is about coverage of the interface, not about speed.
 #include <cstdio>
 #define DN_P 8          // sizes the shared reduction scratch only (Smem<8, 256>)
 #define DN_NT 256
@@ -156,6 +158,122 @@ __device__ __attribute__((noinline)) void nmf_gen(const float *Fb, double *A, do
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One nmf() call when the active matrix has at most NSM columns -- the down-sampled regime of BASELINE config 4
+// (p = 50, take-every 500: 50 x <= 10).  There the small dimension is the column count, and a block-wide pass per
+// inner iteration (nmf_gen: ~37 us each, almost all of it barriers) is the wrong shape.  Here sample s is lane s of
+// wave 0 and keeps its row of x + lambda in registers; the right singular vector v comes from the n x n Gram matrix
+// A^T A = sum over the lanes of a_s a_s^T (what scipy's svds does when n < p) through the same register reduce-scatter
+// and MFMA squaring solver as the templated kernels, with no barrier inside the loop: ~2 us per inner iteration.
+// K E = (A v) v^T, so u_s sigma = a_s . v.  Same outputs as nmf_gen.  The other waves of the workgroup wait.
+// ---------------------------------------------------------------------------------------------------
+constexpr int NSM = 12;
+constexpr int NGS = NSM * (NSM + 1) / 2;      // 78 packed Gram entries
+constexpr int ROWS_ZSLOT = 255;               // last double of g_sm.xw, kept at 0.0 (padding lanes of the solver read it)
+
+__device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, double *sv, double *sj,
+                                                   int n, int S, int T, int first_i, int p)
+{
+    const bool first = first_i != 0;
+    if (wave_id() == 0) {
+        const int lane = lane_id();
+        const bool live = lane < p;
+        double *tot = &g_sm.xw[0][0];                                   // 256 doubles of wave-private scratch here
+        const double inv_s = live ? g_st.inv[lane] : 0.0;
+        double f[NSM], a[NSM], v[NSM];
+#pragma unroll
+        for (int j = 0; j < NSM; j++) {
+            const float xv = (live && j < n) ? Fb[(size_t) lane * S + j] : 0.0f;
+            f[j] = (double) xv * inv_s;
+            a[j] = f[j];                                                // lmbda = 0 (nmf.py:90)
+            v[j] = 0.0;
+        }
+        if (lane == 0) tot[ROWS_ZSLOT] = 0.0;
+        const double c = 1.0 / sqrt((double) T);                        // nmf.py:91
+        EigState<NSM> est;
+        double theta = 0.0;
+        int steps = 0, st = ST_OK;
+#pragma clang loop unroll(disable)
+        for (int t = -1; t < T; t++) {                                  // t = -1: SVD of x itself (nmf.py:88)
+            if (t >= 0) {
+                double ts = 0.0;
+#pragma unroll
+                for (int j = 0; j < NSM; j++) ts = fma(a[j], v[j], ts);  // u_s sigma
+#pragma unroll
+                for (int j = 0; j < NSM; j++) {
+                    const double res = fma(ts, v[j], -f[j]);            // K E - x                       nmf.py:94
+                    a[j] = fmax(fma(-c, res, a[j]), f[j]);              // x + max(lambda - c res, 0)    nmf.py:95-97
+                }
+            }
+            double C[NGS];
+#pragma unroll
+            for (int i = 0; i < NSM; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) C[i * (i + 1) / 2 + j] = a[i] * a[j];
+            {
+                double lo[64], hi[NGS - 64];
+#pragma unroll
+                for (int i = 0; i < 64; i++) lo[i] = C[i];
+#pragma unroll
+                for (int i = 64; i < NGS; i++) hi[i - 64] = C[i];
+                const int e = reduce_scatter_entry(lane);
+                const double s0 = wave_reduce_scatter<64, double>(lo, lane);
+                const double s1 = wave_reduce_scatter<NGS - 64, double>(hi, lane);
+                tot[e] = s0;
+                if (e < NGS - 64) tot[64 + e] = s1;
+            }
+            wave_fence();
+            double tr = 0.0;
+#pragma unroll
+            for (int i = 0; i < NSM; i++) tr += tot[i * (i + 1) / 2 + i];
+            if (!(tr > 0.0)) { st = ST_ARPACK; break; }
+            if (t < 0) eig_state_cold<NSM>(est, tr);
+            wave_fence();
+            if (lane < NSM) tot[lane * (lane + 1) / 2 + lane] -= est.mu;   // the solver takes G - mu I
+            wave_fence();
+            steps += top_eig_mfma<NSM>(tot, ROWS_ZSLOT, v, theta, est, t == T - 1);
+            wave_fence();
+        }
+        if (st == ST_OK) {
+            const double sig = sqrt(theta);
+            double ts = 0.0;
+#pragma unroll
+            for (int j = 0; j < NSM; j++) ts = fma(a[j], v[j], ts);      // u_s sigma for the final state
+            double cs = 0.0, fs = 0.0, ssum = 0.0;
+            double r2[NSM];
+#pragma unroll
+            for (int j = 0; j < NSM; j++) {
+                const double ke = ts * v[j];                            // (K E)_sj
+                cs += ke < f[j] ? f[j] : ke;                            // nmf.py:318
+                fs += f[j];
+                ssum += v[j];
+                double d = ke - f[j];
+                if (!first) d = d < 0.0 ? 0.0 : d;
+                const double r = d / (f[j] + 1.0);                      // nmf.py:282
+                r2[j] = r * r;
+            }
+#pragma unroll
+            for (int j = 0; j < NSM; j++) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) r2[j] = fmax(r2[j], __shfl_xor(r2[j], o));
+            }
+#pragma unroll
+            for (int j = 0; j < NSM; j++) {
+                if (lane == j && j < n) {
+                    const double sk = sig * v[j];                       // s_k = (A^T u)_k
+                    sj[j] = sk;
+                    rs[j] = r2[j];
+                    if (first) sv[j] = sk;
+                }
+            }
+            if (live) { g_st.u[lane] = ts / sig; g_st.csum[lane] = cs; g_st.rsum[lane] = fs; }
+            if (lane == 0) { g_st.theta = theta; g_st.S = sig * ssum; }
+        }
+        if (lane == 0) { g_st.status = st; g_st.steps += steps; }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ double st_max(const double *v, int p) { double m = v[0]; for (int i = 1; i < p; i++) m = v[i] > m ? v[i] : m; return m; }
 __device__ __forceinline__ double st_min(const double *v, int p) { double m = v[0]; for (int i = 1; i < p; i++) m = v[i] < m ? v[i] : m; return m; }
 
@@ -170,7 +288,7 @@ __device__ __forceinline__ int fix_k_lds(int p)
     return ST_OK;
 }
 
-__global__ __launch_bounds__(NT) void k_baseline_gen(IterArgs A)
+__global__ __launch_bounds__(NT, 2) void k_baseline_gen(IterArgs A)      // two workgroups per CU: in the row-wise regime only wave 0 of each works
 {
     constexpr int W = NT / 64;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -271,7 +389,8 @@ __global__ __launch_bounds__(NT) void k_baseline_gen(IterArgs A)
                 int csize = 1, n_bins = 0;
                 bool first = true, in_loop = false;
                 for (;;) {
-                    nmf_gen(Fb, Ast, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    if (n <= NSM) nmf_rows(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    else nmf_gen(Fb, Ast, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
                     if (g_st.status != ST_OK) { status = g_st.status; break; }
                     n_calls++; sum_cols += n;
                     if (first) {
