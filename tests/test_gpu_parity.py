@@ -383,3 +383,37 @@ def test_many_small_ragged_genes_vs_oracle(device, oracle, p):
         est = device.fetch_estimates()
         for a, b in zip(est, est_o):
             np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize('p,rate', [(13, 100), (50, 500), (64, 250), (50, 150)])
+def test_downsampled_wide_cohorts_vs_oracle(device, oracle, p, rate):
+    """
+    The row-wise nmf of the run-time-p kernels (dn_generic.hip, nmf_rows: active matrices of <= 12 columns, one wave per
+    gene) and its hand-over to the block-wide path: with take-every `rate` the genes below have 2 .. 12 active columns,
+    and for rate 150 up to 33 (those go through nmf_gen).  Oracle: same offsets, same parameters.
+    """
+    rng = np.random.default_rng(1000 + p + rate)
+    covs, offs = [], []
+    for k in range(60):
+        L = int(rng.integers(rate + 1, 12 * rate + 1)) if rate != 150 else int(rng.integers(rate + 1, 5001))
+        env = 20.0 + 60.0 * np.abs(np.sin(np.linspace(0, rng.uniform(1, 5), L)))
+        deg = np.ones((p, L))
+        for i in range(p):
+            if rng.random() < 0.4:
+                deg[i] = np.linspace(rng.uniform(0.3, 0.9), 1.0, L)
+        covs.append(rng.poisson(np.outer(rng.lognormal(0, 0.4, p), env) * deg).astype(float))
+        offs.append(int(rng.integers(0, rate)))
+    offs = np.asarray(offs, dtype=np.int64)
+    scale = np.linspace(0.9, 1.1, p)
+    device.upload(covs)
+    rho, flags, trace = device.baseline_iteration(scale, nmf_iter=30, min_high_coverage=2, downsample_rate=rate,
+                                                  ds_start=offs, want_estimates=True)
+    prm = oracle.make_params(nmf_iter=30, min_high_coverage=2, downsample_rate=rate)
+    rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, scale, prm, ds_start=offs, want_estimates=True)
+    np.testing.assert_array_equal(trace[:, [0, 1, 2, 3, 5, 6]], trace_o[:, [0, 1, 2, 3, 5, 6]])
+    np.testing.assert_array_equal(flags, flags_o)
+    np.testing.assert_allclose(rho, rho_o, rtol=1e-8, atol=1e-10)
+    est = device.fetch_estimates()
+    for a, b in zip(est, est_o):
+        np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8)
+    assert trace[:, 0].min() >= 0 and trace[:, 0].max() <= (12 if rate != 150 else 34)
