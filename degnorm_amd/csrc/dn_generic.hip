@@ -535,13 +535,66 @@ __global__ __launch_bounds__(NT, 2) void k_baseline_gen(IterArgs A)      // two 
 }
 
 // ratio_svd + row sums (nmf.py:109-121, :524-525) for run-time p; uses the same scratch slots.
+// y = A (A^T u) on the RAW fp32 coverage (row stride L) in ONE pass: every thread forms s = u . a_j for its columns and
+// adds s a_j to per-thread partials of all p rows (registers), which are then block-reduced in tiles of 8.  The
+// block-wide apply_gram above reads the matrix twice per step from an fp64 copy; the initial pass works on the whole
+// transcript of every gene, so here the bytes are what counts: 4 B per element and step.
+__device__ __forceinline__ double apply_gram_raw(const float *x, int L, int p)
+{
+    const int tid = threadIdx.x;
+    double y[GP];
+#pragma unroll
+    for (int i = 0; i < GP; i++) y[i] = 0.0;
+    for (int k = tid; k < L; k += NT) {
+        float xv[GP];
+#pragma unroll
+        for (int i = 0; i < GP; i++) xv[i] = i < p ? x[(size_t) i * L + k] : 0.0f;
+        double sdot = 0.0;
+#pragma unroll
+        for (int i = 0; i < GP; i++) if (i < p) sdot = fma(g_st.u[i], (double) xv[i], sdot);
+#pragma unroll
+        for (int i = 0; i < GP; i++) if (i < p) y[i] = fma((double) xv[i], sdot, y[i]);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < GP; i0 += TI) {
+        if (i0 < p) {                                                   // uniform
+            double part[TI];
+#pragma unroll
+            for (int r = 0; r < TI; r++) part[r] = y[i0 + r];
+            tile_sum(part);
+            if (tid < TI && i0 + tid < p) g_st.y[i0 + tid] = g_sm.tot[tid];
+            __syncthreads();
+        }
+    }
+    double n2 = 0.0;
+    for (int i = 0; i < p; i++) n2 = fma(g_st.y[i], g_st.y[i], n2);
+    return n2;
+}
+
+__device__ __forceinline__ int top_singular_raw(const float *x, int L, int p)
+{
+    const int tid = threadIdx.x;
+    for (int it = 0; it < 20000; it++) {
+        const double n2 = apply_gram_raw(x, L, p);
+        if (tid == 0) g_st.steps++;
+        if (!(n2 > 0.0)) return ST_ARPACK;
+        const double inv = 1.0 / sqrt(n2);
+        double d2 = 0.0;
+        for (int i = 0; i < p; i++) { const double d = g_st.y[i] * inv - g_st.u[i]; d2 = fma(d, d, d2); }
+        __syncthreads();
+        if (tid < p) g_st.u[tid] = g_st.y[tid] * inv;
+        __syncthreads();
+        if (d2 <= 1e-27) break;
+    }
+    return ST_OK;
+}
+
+// Initial DI pass (nmf.py:109-121, :522-525): top left singular vector of the raw coverage, then the clamped and plain
+// row sums in one more pass (per-thread partials of all rows, reduced in tiles).
 __global__ __launch_bounds__(NT) void k_ratio_svd_gen(InitArgs A)
 {
     const int tid = threadIdx.x;
-    const int p = A.p, S = A.S;
-    char *slot = A.ws + (size_t) blockIdx.x * A.slot_bytes;
-    double *Ast = reinterpret_cast<double *>(slot + (size_t) 2 * p * S * sizeof(float));
-    double *sj = Ast + (size_t) p * S + 2 * (size_t) S;
+    const int p = A.p;
     for (;;) {
         if (tid == 0) g_sm.gene = atomicAdd(A.counter, 1);
         __syncthreads();
@@ -554,38 +607,48 @@ __global__ __launch_bounds__(NT) void k_ratio_svd_gen(InitArgs A)
         int status = ST_OK;
         if (L < 2) status = ST_VALUE_ERROR;
         else {
-            for (int k = tid; k < L; k += NT)
-                for (int i = 0; i < p; i++) Ast[(size_t) i * S + k] = (double) x[(size_t) i * L + k];
             if (tid < p) g_st.u[tid] = 1.0 / sqrt((double) p);
             if (tid == 0) g_st.steps = 0;
             __syncthreads();
-            status = top_singular(Ast, sj, L, S, p);
+            status = top_singular_raw(x, L, p);
         }
-        for (int i0 = 0; i0 < p; i0 += TI) {
-            double pe[TI], pc[TI];
+        double pe[GP], pc[GP];
 #pragma unroll
-            for (int r = 0; r < TI; r++) { pe[r] = 0.0; pc[r] = 0.0; }
-            if (status == ST_OK) {
-                for (int k = tid; k < L; k += NT) {
-                    double s = 0.0;
-                    for (int i = 0; i < p; i++) s = fma(g_st.u[i], Ast[(size_t) i * S + k], s);
+        for (int i = 0; i < GP; i++) { pe[i] = 0.0; pc[i] = 0.0; }
+        if (status == ST_OK) {
+            for (int k = tid; k < L; k += NT) {
+                float xv[GP];
 #pragma unroll
-                    for (int r = 0; r < TI; r++) {
-                        if (i0 + r < p) {
-                            const double v = Ast[(size_t) (i0 + r) * S + k];
-                            const double ke = g_st.u[i0 + r] * s;
-                            pe[r] += ke < v ? v : ke;                         // nmf.py:119
-                            pc[r] += v;
-                        }
+                for (int i = 0; i < GP; i++) xv[i] = i < p ? x[(size_t) i * L + k] : 0.0f;
+                double sdot = 0.0;
+#pragma unroll
+                for (int i = 0; i < GP; i++) if (i < p) sdot = fma(g_st.u[i], (double) xv[i], sdot);
+#pragma unroll
+                for (int i = 0; i < GP; i++) {
+                    if (i < p) {
+                        const double v = (double) xv[i];
+                        const double ke = g_st.u[i] * sdot;
+                        pe[i] += ke < v ? v : ke;                         // nmf.py:119
+                        pc[i] += v;
                     }
                 }
             }
-            tile_sum(pe);
-            if (tid < TI && i0 + tid < p) A.est_sums[(size_t) g * p + i0 + tid] = g_sm.tot[tid];
-            __syncthreads();
-            tile_sum(pc);
-            if (tid < TI && i0 + tid < p) A.cov_sums[(size_t) g * p + i0 + tid] = g_sm.tot[tid];
-            __syncthreads();
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < GP; i0 += TI) {
+            if (i0 < p) {
+                double part[TI];
+#pragma unroll
+                for (int r = 0; r < TI; r++) part[r] = pe[i0 + r];
+                tile_sum(part);
+                if (tid < TI && i0 + tid < p) A.est_sums[(size_t) g * p + i0 + tid] = g_sm.tot[tid];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < TI; r++) part[r] = pc[i0 + r];
+                tile_sum(part);
+                if (tid < TI && i0 + tid < p) A.cov_sums[(size_t) g * p + i0 + tid] = g_sm.tot[tid];
+                __syncthreads();
+            }
         }
         if (tid == 0) A.status[g] = status;
         __syncthreads();

@@ -64,6 +64,19 @@ def test_ratio_svd_sums_vs_oracle(device, oracle):
     np.testing.assert_allclose(est, est_o, rtol=1e-11, atol=1e-8)   # a zero row sums to ~1e-12 (u_i is round-off, not exactly 0)
 
 
+@pytest.mark.parametrize('p', [13, 50, 64])
+def test_ratio_svd_sums_wide_cohorts_vs_oracle(device, oracle, p):
+    """The initial DI pass of the run-time-p kernels (k_ratio_svd_gen: raw fp32 coverage, one fused pass per power step)."""
+    covs = [synth.synth_gene(41, g, p, 300, 4000)[0] for g in range(24)]
+    covs.append(np.vstack([np.zeros((1, 500)), np.random.default_rng(5).poisson(20, size=(p - 1, 500))]).astype(float))   # a zero sample
+    device.upload(covs)
+    est, cov, status = device.ratio_svd_sums()
+    est_o, cov_o, status_o = oracle.ratio_svd_batch(covs)
+    assert not status.any() and not status_o.any()
+    np.testing.assert_allclose(cov, cov_o, rtol=1e-14)
+    np.testing.assert_allclose(est, est_o, rtol=1e-10, atol=1e-7)
+
+
 def _run_fixture(name, **kw):
     from collections import OrderedDict
     from degnorm_amd.nmf import GeneNMFOA
