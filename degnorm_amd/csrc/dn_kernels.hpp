@@ -170,39 +170,41 @@ __device__ __forceinline__ double uniform(double v)
 // (the wave-uniform branches of the state machine rely on that).  Per wave the values are reduce-scattered in
 // registers (dn_reduce.hpp: lane l ends up with the wave total of entry bitrev6(l)), one LDS write per lane hands
 // them to the cross-wave add.
+// One round of the per-wave reduction: entries [OFF, OFF + CNT) of g, CNT <= 64, totals into dst[OFF + entry].
+template <int N, int OFF, typename VT>
+__device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, int lane, double diag_shift, const double *dsel,
+                                                 bool shift_here)
+{
+    constexpr int CNT = (N - OFF) < 64 ? (N - OFF) : 64;
+    VT part[CNT];
+#pragma unroll
+    for (int i = 0; i < CNT; i++) part[i] = g[OFF + i];
+    double s = wave_reduce_scatter<CNT, VT>(part, lane);
+    const int e = reduce_scatter_entry(lane);
+    if (e < CNT) {
+        if (shift_here) s = fma(-diag_shift, dsel[OFF + e], s);
+        dst[OFF + e] = s;
+    }
+    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT>(g, dst, lane, diag_shift, dsel, shift_here);
+}
+
 template <int N, int P, int NT, typename VT, bool SHIFT = false>
 __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm, double diag_shift = 0.0)
 {
-    static_assert(N <= Smem<P, NT>::NX && N <= 128, "xw too small");
+    static_assert(N <= Smem<P, NT>::NX - 1, "xw too small");
     static_assert(!SHIFT || N == P * (P + 1) / 2, "the shift is for the packed Gram matrix");
     constexpr int W = NT / 64;
     const int lane = lane_id(), w = wave_id();
     double *dst = (W > 1) ? sm.xw[w] : sm.tot;
-    const int e = reduce_scatter_entry(lane);
-    if constexpr (N <= 64) {
-        double s = wave_reduce_scatter<N, VT>(g, lane);
-        if constexpr (SHIFT && W == 1) { if (e < N) s = fma(-diag_shift, sm.dsel[e], s); }
-        if (e < N) dst[e] = s;
-    } else {                                                           // p = 11, 12: 66 / 78 Gram entries, two rounds
-        VT lo[64], hi[N - 64];
-#pragma unroll
-        for (int i = 0; i < 64; i++) lo[i] = g[i];
-#pragma unroll
-        for (int i = 64; i < N; i++) hi[i - 64] = g[i];
-        double s0 = wave_reduce_scatter<64, VT>(lo, lane);
-        double s1 = wave_reduce_scatter<N - 64, VT>(hi, lane);
-        if constexpr (SHIFT && W == 1) { s0 = fma(-diag_shift, sm.dsel[e], s0); if (e < N - 64) s1 = fma(-diag_shift, sm.dsel[64 + e], s1); }
-        dst[e] = s0;
-        if (e < N - 64) dst[64 + e] = s1;
-    }
+    wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel, SHIFT && W == 1);     // ceil(N / 64) rounds
     if constexpr (W > 1) {
         __syncthreads();
-        if (threadIdx.x < N) {
-            double t = sm.xw[0][threadIdx.x];
+        for (int e = threadIdx.x; e < N; e += NT) {                     // one trip unless N > NT (p >= 16 on 128 threads)
+            double t = sm.xw[0][e];
 #pragma unroll
-            for (int ww = 1; ww < W; ww++) t += sm.xw[ww][threadIdx.x];
-            if constexpr (SHIFT) t = fma(-diag_shift, sm.dsel[threadIdx.x], t);     // G - mu I for the eigen-solver
-            sm.tot[threadIdx.x] = t;
+            for (int ww = 1; ww < W; ww++) t += sm.xw[ww][e];
+            if constexpr (SHIFT) t = fma(-diag_shift, sm.dsel[e], t);                // G - mu I for the eigen-solver
+            sm.tot[e] = t;
         }
     }
     __syncthreads();
