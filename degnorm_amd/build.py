@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'obj')
 LIB = os.path.join(HERE, 'libdegnorm_amd.so')
-P_LIST = list(range(2, 13))          # keep in sync with DN_FOR_EACH_P in csrc/dn_api.hip
+P_LIST = list(range(2, int(os.environ.get('DN_P_MAX_TEMPLATED', 16)) + 1))   # keep in sync with DN_FOR_EACH_P in csrc/dn_api.hip
 ARCH = 'gfx950'
 WIDE_NT = int(os.environ.get('DN_WIDE_NT', 256))     # wide-class workgroup size (csrc/dn_api.hip DN_WIDE_NT)
 NT_LIST = (WIDE_NT, 128)
@@ -77,7 +77,7 @@ def build_library(force=False, verbose=False):
     o_api = os.path.join(OBJ, 'dn_api.o')
     objs.append(o_api)
     if force or _newer(o_api, [api] + hdr):
-        jobs.append([hipcc] + FLAGS + ['-DDN_WIDE_NT={0}'.format(WIDE_NT), '-c', api, '-o', o_api])
+        jobs.append([hipcc] + FLAGS + ['-DDN_WIDE_NT={0}'.format(WIDE_NT), '-DDN_P_MAX_TEMPLATED={0}'.format(P_LIST[-1]), '-c', api, '-o', o_api])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for out in ex.map(_run, jobs):

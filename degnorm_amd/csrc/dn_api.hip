@@ -15,7 +15,14 @@
 #include <vector>
 
 // sample counts with compiled kernels (dn_inst.hip is built once per entry; keep in sync with build.py)
+#ifndef DN_P_MAX_TEMPLATED
+#define DN_P_MAX_TEMPLATED 16        // one 16 x 16 fp64 MFMA tile holds the Gram matrix of the eigen-solver
+#endif
+#if DN_P_MAX_TEMPLATED >= 16
+#define DN_FOR_EACH_P(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#else
 #define DN_FOR_EACH_P(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#endif
 
 namespace dn {
 #ifndef DN_WIDE_NT
@@ -49,7 +56,7 @@ const KernelSet *kernel_set_for(int p)
 #define DN_CASE(P) case P: return DN_WIDE_SET(P)();
         DN_FOR_EACH_P(DN_CASE)
 #undef DN_CASE
-        default: return (p > 12 && p <= P_MAX) ? kernel_set_generic() : nullptr;
+        default: return (p > DN_P_MAX_TEMPLATED && p <= P_MAX) ? kernel_set_generic() : nullptr;
     }
 }
 }  // namespace dn

@@ -232,9 +232,9 @@ def test_full_size_head_vs_oracle(device, oracle):
     np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
 
 
-@pytest.mark.parametrize('p', [2, 3, 7, 12, 13, 20])
+@pytest.mark.parametrize('p', [2, 3, 7, 12, 13, 14, 16, 17, 20])
 def test_sample_counts_and_edge_shapes_vs_oracle(device, oracle, p):
-    """Every compiled sample count family (templated 2..12, run-time-p above) on ragged / tiny / single-gene inputs."""
+    """Every compiled sample count family (templated 2..16, run-time-p above) on ragged / tiny / single-gene inputs."""
     rng = np.random.default_rng(100 + p)
     covs = [synth.synth_gene(9, g, p, 60, 900)[0] for g in range(10)]
     covs += [rng.poisson(30, size=(p, L)).astype(float) for L in (2, 3, 5, 51, 64, 65, 257)]     # tiny and boundary lengths
