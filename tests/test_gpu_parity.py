@@ -367,7 +367,7 @@ def test_eigen_solver_hard_spectra_vs_oracle(device, oracle):
     assert trace[:, 7].max() < 4000 * 41 * max(1, int(trace[:, 1].max()))       # the step cap was not what ended the solves
 
 
-@pytest.mark.parametrize('p', [5, 10])
+@pytest.mark.parametrize('p', [5, 10, 15])
 def test_many_small_ragged_genes_vs_oracle(device, oracle, p):
     """
     300 genes of every small length (2 .. 420 bases, around the 64 / 128 / 256 lane and wave boundaries) with three
