@@ -188,18 +188,18 @@ __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, 
     if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT>(g, dst, lane, diag_shift, dsel, shift_here);
 }
 
-template <int N, int P, int NT, typename VT, bool SHIFT = false>
+template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0>    // OFF: the totals go to tot[OFF .. OFF + N)
 __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm, double diag_shift = 0.0)
 {
-    static_assert(N <= Smem<P, NT>::NX - 1, "xw too small");
-    static_assert(!SHIFT || N == P * (P + 1) / 2, "the shift is for the packed Gram matrix");
+    static_assert(OFF + N <= Smem<P, NT>::NX - 1, "xw too small");
+    static_assert(!SHIFT || OFF + N <= P * (P + 1) / 2, "the shift is for the packed Gram matrix");
     constexpr int W = NT / 64;
     const int lane = lane_id(), w = wave_id();
-    double *dst = (W > 1) ? sm.xw[w] : sm.tot;
-    wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel, SHIFT && W == 1);     // ceil(N / 64) rounds
+    double *dst = ((W > 1) ? sm.xw[w] : sm.tot) + OFF;
+    wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1);     // ceil(N / 64) rounds
     if constexpr (W > 1) {
         __syncthreads();
-        for (int e = threadIdx.x; e < N; e += NT) {                     // one trip unless N > NT (p >= 16 on 128 threads)
+        for (int e = OFF + threadIdx.x; e < OFF + N; e += NT) {         // one trip unless N > NT
             double t = sm.xw[0][e];
 #pragma unroll
             for (int ww = 1; ww < W; ww++) t += sm.xw[ww][e];
@@ -489,6 +489,23 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
 
 typedef DN_GRAM_T gram_t;      // per-lane Gram accumulators: double (exact mode) or float (mixed mode)
 
+// Packed entries [LO, LO + CNT) of the Gram update only (a sweep of a Gram matrix too large for one register set).
+template <int P, int LO, int CNT, typename T>
+__device__ __forceinline__ void gram_add_range(T (&G)[CNT], const double (&a)[P])
+{
+    T b[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) b[i] = (T) a[i];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            constexpr int dummy = 0; (void) dummy;
+            const int idx = i * (i + 1) / 2 + j;
+            if (idx >= LO && idx < LO + CNT) G[idx - LO] = fma(b[i], b[j], G[idx - LO]);
+        }
+}
+
 template <int P, typename T>
 __device__ __forceinline__ void gram_add(T (&G)[P * (P + 1) / 2], const double (&a)[P])
 {
@@ -583,8 +600,7 @@ typedef double __attribute__((address_space(1))) *gdouble_ptr;
 // with s = u . a (E_j sigma), so a pass costs 3 fp64 ops per element plus the p(p+1)/2 Gram products and
 // x + lambda is never re-formed (nmf.py:97).  lambda is not needed by itself anywhere.
 template <int P>
-__device__ __forceinline__ void col_step(const double (&f)[P], double (&a)[P], const double (&u)[P], double c,
-                                         gram_t (&G)[P * (P + 1) / 2])
+__device__ __forceinline__ void col_update(const double (&f)[P], double (&a)[P], const double (&u)[P], double c)
 {
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -596,7 +612,6 @@ __device__ __forceinline__ void col_step(const double (&f)[P], double (&a)[P], c
         const double res = fma(u[i], s, -f[i]);                        // est - x                       nmf.py:94
         a[i] = fmax(fma(-c, res, a[i]), f[i]);                         // x + max(lambda - c res, 0)    nmf.py:95-97
     }
-    gram_add<P>(G, a);
 }
 
 template <int P>
@@ -711,21 +726,42 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #define DN_T1(slot) (void) stamp
 #endif
     constexpr int NG = P * (P + 1) / 2;
+    // The Gram matrix is accumulated in SW sweeps of at most CH packed entries: one register set holds ~105 fp64
+    // accumulators next to the column in flight (p <= 15, the last of them already through AGPR copies); p = 16 takes a
+    // second, read-only sweep over the updated state (+9 % there; at p = 15 the second sweep costs more than the copies).
+    constexpr int SW = (NG + 119) / 120;
+    constexpr int CH = (NG + SW - 1) / SW;
+    static_assert(SW <= 2, "more sweeps: generalise the code below");
+    constexpr int N1 = NG - CH;                            // entries of the second sweep (0: none)
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
     const int tid = threadIdx.x;
     const int nLe = (n < nL) ? n : nL;                     // end of the LDS tier
-    gram_t G[NG];
+    gram_t G[CH];
 
     // cold start: SVD of x itself (nmf.py:88)
 #pragma unroll
-    for (int i = 0; i < NG; i++) G[i] = 0.0;
+    for (int i = 0; i < CH; i++) G[i] = 0.0;
 #pragma clang loop unroll(disable)
     for (int k = tid; k < n; k += NT) {
         double f[P];
         load_f<P>(Fb, k, inv, f);
-        gram_add<P>(G, f);
+        gram_add_range<P, 0, CH>(G, f);
     }
-    block_sum_lds<NG, P, NT, gram_t>(G, sm);
+    block_sum_lds<CH, P, NT, gram_t>(G, sm);
+    if constexpr (SW > 1) {
+#pragma unroll
+        for (int i = 0; i < CH; i++) G[i] = 0.0;
+#pragma clang loop unroll(disable)
+        for (int k = tid; k < n; k += NT) {
+            double f[P];
+            load_f<P>(Fb, k, inv, f);
+            gram_add_range<P, CH, CH>(G, f);
+        }
+        gram_t G1[N1 > 0 ? N1 : 1];
+#pragma unroll
+        for (int i = 0; i < N1; i++) G1[i] = G[i];
+        block_sum_lds<(N1 > 0 ? N1 : 1), P, NT, gram_t, false, (N1 > 0 ? CH : 0)>(G1, sm);
+    }
     {
         double tr = 0.0;
 #pragma unroll
@@ -754,7 +790,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
 #pragma unroll
-        for (int i = 0; i < NG; i++) G[i] = 0.0;
+        for (int i = 0; i < CH; i++) G[i] = 0.0;
         { DN_T0();
         // The columns are walked forwards on even passes and backwards on odd ones (spill tier first, then the LDS tier):
         // what the previous pass touched last -- the end of the spill state and of the counts -- is still in the XCD's
@@ -787,7 +823,8 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
-                col_step<P>(f, aa, u, c, G);
+                col_update<P>(f, aa, u, c);
+                gram_add_range<P, 0, CH>(G, aa);
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
                 lds_col_write<PS>(lam + (size_t) k * PS, a);
@@ -821,7 +858,8 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                         for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k + step) + i * 64);
                     }
                 }
-                col_step<P>(f, a, u, c, G);
+                col_update<P>(f, a, u, c);
+                gram_add_range<P, 0, CH>(G, a);
 #pragma unroll
                 for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], spill_ptr<P>(Lg, k) + i * 64);
             }
@@ -829,7 +867,31 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         if (dir > 0) { lds_tier(); spill_tier(); }
         else { spill_tier(); lds_tier(); }
         DN_T1(0); }
-        { DN_T0(); block_sum_lds<NG, P, NT, gram_t, true>(G, sm, est.mu); DN_T1(1); }       // tot = G - mu I
+        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, true>(G, sm, est.mu); DN_T1(1); }       // tot = G - mu I
+        if constexpr (SW > 1) {
+            // second sweep (p = 15, 16): the remaining Gram entries from the updated state, read-only
+#pragma unroll
+            for (int i = 0; i < CH; i++) G[i] = 0.0;
+#pragma clang loop unroll(disable)
+            for (int k = tid; k < nLe; k += NT) {
+                double a[PS], aa[P];
+                lds_col_read<PS>(lam + (size_t) k * PS, a);
+#pragma unroll
+                for (int i = 0; i < P; i++) aa[i] = a[i];
+                gram_add_range<P, CH, CH>(G, aa);
+            }
+#pragma clang loop unroll(disable)
+            for (int k = nL + tid; k < n; k += NT) {
+                double aa[P];
+#pragma unroll
+                for (int i = 0; i < P; i++) aa[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
+                gram_add_range<P, CH, CH>(G, aa);
+            }
+            gram_t G1[N1 > 0 ? N1 : 1];
+#pragma unroll
+            for (int i = 0; i < N1; i++) G1[i] = G[i];
+            block_sum_lds<(N1 > 0 ? N1 : 1), P, NT, gram_t, true, (N1 > 0 ? CH : 0)>(G1, sm, est.mu);
+        }
         { DN_T0();
         steps += top_eig_mfma<P>(sm.tot, Smem<P, NT>::ZSLOT, u, theta, est, t == T - 1);   // sigma^2 is only read after the last solve
 #pragma unroll
