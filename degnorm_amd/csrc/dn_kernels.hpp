@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "dn_reduce.hpp"
 
 // Spill-tier accesses: the x + lambda columns that do not fit on chip are re-read only after a whole pass, far
@@ -487,6 +488,118 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
     return steps + 1;
 }
 
+// Sample counts above 16 (more than one MFMA tile): shifted power iteration with the matrix distributed by rows --
+// lane l keeps row l of G, computes one component of G v per step, v_readlane broadcasts the p components.  Two
+// unnormalised steps between convergence checks; the check predicts the current error from the contraction between
+// consecutive checks and stops at ~1e-13.  Warm-started from u.  All waves run it redundantly on identical data.
+template <int P>
+__device__ __forceinline__ void bcast_rows(double y, double (&yb)[P])
+{
+    const int lo = __double2loint(y), hi = __double2hiint(y);
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        yb[j] = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+}
+
+template <int P>
+__device__ __forceinline__ double row_dot(const double (&Gr)[P], const double (&v)[P])
+{
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j + 1 < P; j += 2) { a0 = fma(Gr[j], v[j], a0); a1 = fma(Gr[j + 1], v[j + 1], a1); }
+    if (P & 1) a0 = fma(Gr[P - 1], v[P - 1], a0);
+    return a0 + a1;
+}
+
+template <int P>
+__device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], double &theta)
+{
+    static_assert(P <= 64, "one row per lane");
+    const int r = lane_id() < P ? lane_id() : P - 1;
+    double Gr[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const int a = r > j ? r : j, b = r > j ? j : r;
+        Gr[j] = tot[a * (a + 1) / 2 + b];
+    }
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) tr += tot[i * (i + 1) / 2 + i];
+
+    double v[P], w[P];
+    bcast_rows<P>(row_dot<P>(Gr, u), w);                               // w = G u
+    double th = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) th = fma(u[i], w[i], th);
+    if (!(th > 0.0)) { theta = 0.0; return 1; }
+    double mu = (tr - th) * (1.0 / (double) (P > 1 ? P - 1 : 1));
+    mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
+#pragma unroll
+    for (int j = 0; j < P; j++) Gr[j] = (j == r) ? Gr[j] - mu : Gr[j];  // G - mu I
+#pragma unroll
+    for (int i = 0; i < P; i++) v[i] = fma(-mu, u[i], w[i]);             // first shifted step
+    int steps = 1;
+    double d2_prev = -1.0;
+    for (;;) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) n2 = fma(v[i], v[i], n2);
+        if (!(n2 > 0.0)) { theta = 0.0; return steps; }
+        const double inv = rsqrt_newton(n2);
+        double d2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const double un = v[i] * inv;
+            const double d = un - u[i];
+            d2 = fma(d, d, d2);
+            u[i] = un;
+        }
+        if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev) || steps >= 4000) break;
+        d2_prev = d2;
+        bcast_rows<P>(row_dot<P>(Gr, u), w);                           // two plain steps, no normalisation in between
+        bcast_rows<P>(row_dot<P>(Gr, w), v);
+        steps += 2;
+    }
+    bcast_rows<P>(row_dot<P>(Gr, u), w);                               // Rayleigh quotient of the unshifted matrix
+    th = mu;
+#pragma unroll
+    for (int i = 0; i < P; i++) th = fma(u[i], w[i], th);
+    theta = th;
+    return steps + 1;
+}
+
+// One interface over the two solvers: the MFMA squaring solver with its carried state for p <= 16, the row-distributed
+// power iteration above it.
+template <int P, bool MFMA = (P <= 16)> struct Solver;
+template <int P> struct Solver<P, true> {
+    EigState<P> st;
+    __device__ __forceinline__ void cold(double tr, double (&u)[P]) { (void) u; eig_state_cold<P>(st, tr); }
+    __device__ __forceinline__ double shift() const { return st.mu; }
+    static constexpr bool SHIFTED = true;
+    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact)
+    { return top_eig_mfma<P>(tot, zslot, u, theta, st, exact); }
+};
+template <int P> struct Solver<P, false> {
+    __device__ __forceinline__ void cold(double tr, double (&u)[P])
+    {
+        (void) tr;
+        const double u0 = 1.0 / sqrt((double) P);
+#pragma unroll
+        for (int i = 0; i < P; i++) u[i] = u0;
+    }
+    __device__ __forceinline__ double shift() const { return 0.0; }
+    static constexpr bool SHIFTED = false;
+    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact)
+    { (void) zslot; (void) exact; return top_eig_rows<P>(tot, u, theta); }
+};
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
+template <int I, int I1, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < I1) { f(std::integral_constant<int, I>{}); static_for<I + 1, I1>(f); }
+}
+
 typedef DN_GRAM_T gram_t;      // per-lane Gram accumulators: double (exact mode) or float (mixed mode)
 
 // Packed entries [LO, LO + CNT) of the Gram update only (a sweep of a Gram matrix too large for one register set).
@@ -726,13 +839,13 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #define DN_T1(slot) (void) stamp
 #endif
     constexpr int NG = P * (P + 1) / 2;
-    // The Gram matrix is accumulated in SW sweeps of at most CH packed entries: one register set holds ~105 fp64
-    // accumulators next to the column in flight (p <= 15, the last of them already through AGPR copies); p = 16 takes a
-    // second, read-only sweep over the updated state (+9 % there; at p = 15 the second sweep costs more than the copies).
-    constexpr int SW = (NG + 119) / 120;
+    // The Gram matrix is accumulated in SW sweeps of CH packed entries each: one register set holds ~105-120 fp64
+    // accumulators next to the column in flight (p <= 15, the last of them already through AGPR copies).  From p = 16 on
+    // the first sweep updates the state and later sweeps re-read it (read-only) for the remaining entries; the budget per
+    // sweep shrinks with p because the column in flight (state, counts, F) takes 5 p registers.
+    constexpr int CH_MAX = P <= 15 ? 120 : (P == 16 ? 68 : ((232 - 5 * P) / 2 > 32 ? (232 - 5 * P) / 2 : 32));
+    constexpr int SW = (NG + CH_MAX - 1) / CH_MAX;
     constexpr int CH = (NG + SW - 1) / SW;
-    static_assert(SW <= 2, "more sweeps: generalise the code below");
-    constexpr int N1 = NG - CH;                            // entries of the second sweep (0: none)
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
     const int tid = threadIdx.x;
     const int nLe = (n < nL) ? n : nL;                     // end of the LDS tier
@@ -748,34 +861,34 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         gram_add_range<P, 0, CH>(G, f);
     }
     block_sum_lds<CH, P, NT, gram_t>(G, sm);
-    if constexpr (SW > 1) {
+    static_for<1, SW>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int NQ = (NG - Q * CH) < CH ? (NG - Q * CH) : CH;
+        gram_t Gq[NQ];
 #pragma unroll
-        for (int i = 0; i < CH; i++) G[i] = 0.0;
+        for (int i = 0; i < NQ; i++) Gq[i] = 0.0;
 #pragma clang loop unroll(disable)
         for (int k = tid; k < n; k += NT) {
             double f[P];
             load_f<P>(Fb, k, inv, f);
-            gram_add_range<P, CH, CH>(G, f);
+            gram_add_range<P, Q * CH, NQ>(Gq, f);
         }
-        gram_t G1[N1 > 0 ? N1 : 1];
-#pragma unroll
-        for (int i = 0; i < N1; i++) G1[i] = G[i];
-        block_sum_lds<(N1 > 0 ? N1 : 1), P, NT, gram_t, false, (N1 > 0 ? CH : 0)>(G1, sm);
-    }
+        block_sum_lds<NQ, P, NT, gram_t, false, Q * CH>(Gq, g_sm);
+    });
     {
         double tr = 0.0;
 #pragma unroll
         for (int i = 0; i < P; i++) tr += sm.tot[i * (i + 1) / 2 + i];
         if (!(tr > 0.0)) { if (tid == 0) g_gs.status = ST_ARPACK; __syncthreads(); return; }
     }
-    EigState<P> est;
+    Solver<P> solver;
     {
         double tr = 0.0;
 #pragma unroll
         for (int i = 0; i < P; i++) tr += sm.tot[i * (i + 1) / 2 + i];
-        eig_state_cold<P>(est, tr);
+        solver.cold(tr, u);
     }
-    steps += top_eig_mfma<P>(sm.tot, Smem<P, NT>::ZSLOT, u, theta, est, T == 0);
+    steps += solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, T == 0);
 #pragma unroll
     for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
 
@@ -867,33 +980,33 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         if (dir > 0) { lds_tier(); spill_tier(); }
         else { spill_tier(); lds_tier(); }
         DN_T1(0); }
-        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, true>(G, sm, est.mu); DN_T1(1); }       // tot = G - mu I
-        if constexpr (SW > 1) {
-            // second sweep (p = 15, 16): the remaining Gram entries from the updated state, read-only
+        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
+        // later sweeps (p >= 16): the remaining Gram entries from the updated state, read-only
+        static_for<1, SW>([&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            constexpr int NQ = (NG - Q * CH) < CH ? (NG - Q * CH) : CH;
+            gram_t Gq[NQ];
 #pragma unroll
-            for (int i = 0; i < CH; i++) G[i] = 0.0;
+            for (int i = 0; i < NQ; i++) Gq[i] = 0.0;
 #pragma clang loop unroll(disable)
             for (int k = tid; k < nLe; k += NT) {
                 double a[PS], aa[P];
                 lds_col_read<PS>(lam + (size_t) k * PS, a);
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
-                gram_add_range<P, CH, CH>(G, aa);
+                gram_add_range<P, Q * CH, NQ>(Gq, aa);
             }
 #pragma clang loop unroll(disable)
             for (int k = nL + tid; k < n; k += NT) {
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
-                gram_add_range<P, CH, CH>(G, aa);
+                gram_add_range<P, Q * CH, NQ>(Gq, aa);
             }
-            gram_t G1[N1 > 0 ? N1 : 1];
-#pragma unroll
-            for (int i = 0; i < N1; i++) G1[i] = G[i];
-            block_sum_lds<(N1 > 0 ? N1 : 1), P, NT, gram_t, true, (N1 > 0 ? CH : 0)>(G1, sm, est.mu);
-        }
+            block_sum_lds<NQ, P, NT, gram_t, Solver<P>::SHIFTED, Q * CH>(Gq, g_sm, solver.shift());
+        });
         { DN_T0();
-        steps += top_eig_mfma<P>(sm.tot, Smem<P, NT>::ZSLOT, u, theta, est, t == T - 1);   // sigma^2 is only read after the last solve
+        steps += solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, t == T - 1);   // sigma^2 is only read after the last solve
 #pragma unroll
         for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
         DN_T1(2); }
