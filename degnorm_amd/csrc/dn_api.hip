@@ -16,12 +16,25 @@
 
 // sample counts with compiled kernels (dn_inst.hip is built once per entry; keep in sync with build.py)
 #ifndef DN_P_MAX_TEMPLATED
-#define DN_P_MAX_TEMPLATED 16        // one 16 x 16 fp64 MFMA tile holds the Gram matrix of the eigen-solver
+#define DN_P_MAX_TEMPLATED 32        // templated kernels for 2 .. this many samples (build.py compiles the same list)
 #endif
-#if DN_P_MAX_TEMPLATED >= 16
-#define DN_FOR_EACH_P(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#define DN_P_2_16(X)  X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#define DN_P_17_24(X) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+#define DN_P_25_32(X) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+#define DN_P_33_48(X) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48)
+#define DN_P_49_64(X) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
+#if DN_P_MAX_TEMPLATED >= 64
+#define DN_FOR_EACH_P(X) DN_P_2_16(X) DN_P_17_24(X) DN_P_25_32(X) DN_P_33_48(X) DN_P_49_64(X)
+#elif DN_P_MAX_TEMPLATED >= 48
+#define DN_FOR_EACH_P(X) DN_P_2_16(X) DN_P_17_24(X) DN_P_25_32(X) DN_P_33_48(X)
+#elif DN_P_MAX_TEMPLATED >= 32
+#define DN_FOR_EACH_P(X) DN_P_2_16(X) DN_P_17_24(X) DN_P_25_32(X)
+#elif DN_P_MAX_TEMPLATED >= 24
+#define DN_FOR_EACH_P(X) DN_P_2_16(X) DN_P_17_24(X)
+#elif DN_P_MAX_TEMPLATED >= 16
+#define DN_FOR_EACH_P(X) DN_P_2_16(X)
 #else
-#define DN_FOR_EACH_P(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#error "DN_P_MAX_TEMPLATED must be 16, 24, 32, 48 or 64"
 #endif
 
 namespace dn {

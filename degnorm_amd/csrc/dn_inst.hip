@@ -32,7 +32,11 @@ static int launch_baseline(const IterArgs &a, int grid, size_t dyn_lds, hipStrea
 
 static void launch_init(const InitArgs &a, int grid, hipStream_t s)
 {
+#if DN_P <= 16
     hipLaunchKernelGGL((k_ratio_svd<DN_P, DN_NT>), dim3(grid), dim3(DN_NT), 0, s, a);
+#else
+    kernel_set_generic()->init(a, grid, s);      // the per-lane p x p Gram of k_ratio_svd does not fit in registers above 16
+#endif
 }
 
 static void launch_est(const EstArgs &a, const int32_t *tg, const int32_t *tc, int n_tiles, hipStream_t s)
@@ -45,7 +49,11 @@ static int blocks_per_cu(int which)
     int nb = 0;
     hipError_t e;
     if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline<DN_P, DN_NT>, DN_NT, 0);
+#if DN_P <= 16
     else            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd<DN_P, DN_NT>, DN_NT, 0);
+#else
+    else return kernel_set_generic()->blocks_per_cu(1);
+#endif
     return e == hipSuccess ? nb : 0;
 }
 

@@ -232,9 +232,10 @@ def test_full_size_head_vs_oracle(device, oracle):
     np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
 
 
-@pytest.mark.parametrize('p', [2, 3, 7, 12, 13, 14, 16, 17, 20])
+@pytest.mark.parametrize('p', [2, 3, 7, 12, 13, 14, 16, 17, 20, 24, 31, 32, 33, 40])
 def test_sample_counts_and_edge_shapes_vs_oracle(device, oracle, p):
-    """Every compiled sample count family (templated 2..16, run-time-p above) on ragged / tiny / single-gene inputs."""
+    """Every compiled sample count family (templated 2..32: one / several Gram sweeps, MFMA / row solver; run-time-p above)
+    on ragged / tiny / single-gene inputs."""
     rng = np.random.default_rng(100 + p)
     covs = [synth.synth_gene(9, g, p, 60, 900)[0] for g in range(10)]
     covs += [rng.poisson(30, size=(p, L)).astype(float) for L in (2, 3, 5, 51, 64, 65, 257)]     # tiny and boundary lengths
@@ -367,7 +368,7 @@ def test_eigen_solver_hard_spectra_vs_oracle(device, oracle):
     assert trace[:, 7].max() < 4000 * 41 * max(1, int(trace[:, 1].max()))       # the step cap was not what ended the solves
 
 
-@pytest.mark.parametrize('p', [5, 10, 15])
+@pytest.mark.parametrize('p', [5, 10, 15, 22])
 def test_many_small_ragged_genes_vs_oracle(device, oracle, p):
     """
     300 genes of every small length (2 .. 420 bases, around the 64 / 128 / 256 lane and wave boundaries) with three
