@@ -841,9 +841,10 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     constexpr int NG = P * (P + 1) / 2;
     // The Gram matrix is accumulated in SW sweeps of CH packed entries each: one register set holds ~105-120 fp64
     // accumulators next to the column in flight (p <= 15, the last of them already through AGPR copies).  From p = 16 on
-    // the first sweep updates the state and later sweeps re-read it (read-only) for the remaining entries; the budget per
-    // sweep shrinks with p because the column in flight (state, counts, F) takes 5 p registers.
-    constexpr int CH_MAX = P <= 15 ? 120 : (P == 16 ? 68 : ((232 - 5 * P) / 2 > 32 ? (232 - 5 * P) / 2 : 32));
+    // the first sweep updates the state and later sweeps re-read it (read-only) for the remaining entries.  ~90 entries
+    // per sweep measured best at p = 20 and p = 32 alike (36 / 53 / 70 / 90 / 105 / 132 / 176 tried: fewer, fatter
+    // sweeps trade state re-reads for AGPR copies; beyond ~105 the accumulators reach scratch memory).
+    constexpr int CH_MAX = P <= 15 ? 120 : 90;
     constexpr int SW = (NG + CH_MAX - 1) / CH_MAX;
     constexpr int CH = (NG + SW - 1) / SW;
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
