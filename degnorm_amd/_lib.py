@@ -52,6 +52,7 @@ def load(build_if_missing=False):
     lib.dn_destroy.argtypes = [vp]
     lib.dn_upload_ragged.argtypes = [vp, i64, i32, P(vp), P(i64), i32, i32, P(i64)]
     lib.dn_upload_packed.argtypes = [vp, i64, i32, P(c.c_float), P(i64)]
+    lib.dn_set_downsample_hint.argtypes = [vp, i32]
     lib.dn_ratio_svd_sums.argtypes = [vp, P(dbl), P(dbl), P(i32)]
     lib.dn_baseline_iteration.argtypes = [vp, P(dbl), P(Params), P(i64), P(dbl), P(i32), P(i32)]
     lib.dn_fetch_estimates.argtypes = [vp, P(dbl)]
@@ -118,6 +119,11 @@ class Device:
             pass
 
     # -- upload ------------------------------------------------------------------------------------
+    def hint_downsample(self, rate):
+        """Announce the take-every rate before an upload (kernel-family choice only; see dn_set_downsample_hint)."""
+        _check(self.lib.dn_set_downsample_hint(self.h, int(max(1, rate))))
+        return self
+
     def upload(self, cov_mats, n_threads=0):
         """cov_mats: list of (p x L_g) float64 or float32 arrays (reference layout, nmf.py:488-490)."""
         n = len(cov_mats)

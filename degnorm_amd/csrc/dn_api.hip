@@ -148,6 +148,7 @@ struct dn_handle_s {
     double last_scale[dn::P_MAX] = {0};
     bool have_estimate_state = false;
     float last_ms = 0.f;
+    int32_t ds_hint = 1;          // take-every rate the caller intends to use (dn_set_downsample_hint); 1 = none
     // per-gene counters of the previous dn_baseline_iteration: the narrow class orders its queue by the work they predict
     std::vector<int32_t> host_trace;
     bool have_trace = false;
@@ -359,6 +360,7 @@ static int check_shape(dn_handle h, int64_t n_genes, int32_t p, const int64_t *l
     const dn::KernelSet *ks = dn::kernel_set_for(p);
     if (!ks) return fail(DN_E_UNSUPPORTED, "no kernels compiled for p = " + std::to_string(p));
     h->ks = ks;
+    bool rows_regime = h->ds_hint > 1 && p >= 8;
     h->n = n_genes; h->p = p;
     h->goff.assign(n_genes + 1, 0);
     h->glen.assign(n_genes, 0);
@@ -371,6 +373,18 @@ static int check_shape(dn_handle h, int64_t n_genes, int32_t p, const int64_t *l
     }
     h->total = h->goff[n_genes];
     h->lmax = lmax;
+    // Down-sampled regime announced by the caller: when no gene can keep more than 12 active columns the run-time-p
+    // kernels serve it row-wise, one wave per gene (dn_generic.hip, nmf_rows) -- faster than the column-parallel
+    // templated kernels from p ~ 8 on (p = 16: 76 000 vs 41 000 genes/s per run, p = 32: 5x).
+    if (rows_regime && (lmax + h->ds_hint - 1) / h->ds_hint <= 12) h->ks = dn::kernel_set_generic();
+    return DN_OK;
+}
+
+int dn_set_downsample_hint(dn_handle h, int32_t rate)
+{
+    if (!h) return fail(DN_E_INVALID, "null handle");
+    if (rate < 1) return fail(DN_E_INVALID, "downsample rate must be >= 1");
+    h->ds_hint = rate;
     return DN_OK;
 }
 

@@ -114,6 +114,7 @@ class GeneNMFOA(object):
 
         dev = _lib.Device(self.device)
         self._dev = dev
+        dev.hint_downsample(self.downsample_rate)
         dev.upload(cov_mats, n_threads=max(self.n_jobs, 0))
         if dev.inexact:
             warnings.warn('{0} coverage values are not exactly representable in float32; '

@@ -159,10 +159,14 @@ class ShardedNMFOA(object):
 
     # -- data -------------------------------------------------------------------------------------
     def load(self, cov_mats, reads):
+        if hasattr(self.dev, 'hint_downsample'):
+            self.dev.hint_downsample(self.downsample_rate)
         self.dev.upload(cov_mats)
         self._set_reads(reads)
 
     def load_packed(self, packed, lengths, p, reads):
+        if hasattr(self.dev, 'hint_downsample'):
+            self.dev.hint_downsample(self.downsample_rate)
         self.dev.upload_packed(packed, lengths, p)
         self._set_reads(reads)
 

@@ -71,6 +71,10 @@ int  dn_destroy(dn_handle h);
  * or float32 (is_f32 = 1).  *inexact (nullable) receives the number of values that are not exactly
  * representable in float32 (DegNorm coverage is integer counts, reads.py:714,773, so normally 0).
  * dn_upload_packed: the same data already packed (offsets in elements, offsets[n] = total).          */
+/* Optional, before an upload: the take-every rate the following dn_baseline_iteration calls will use (GeneNMFOA's
+ * downsample_rate, nmf.py:36).  Only steers which kernel family serves the data (results do not depend on it): when no
+ * gene can keep more than 12 active columns, the row-wise one-wave-per-gene kernels are chosen from p = 8 on.          */
+int  dn_set_downsample_hint(dn_handle h, int32_t rate);
 int  dn_upload_ragged(dn_handle h, int64_t n_genes, int32_t p, const void *const *genes,
                       const int64_t *lengths, int32_t is_f32, int32_t n_threads, int64_t *inexact);
 int  dn_upload_packed(dn_handle h, int64_t n_genes, int32_t p, const float *packed,

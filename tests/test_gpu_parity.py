@@ -431,3 +431,28 @@ def test_downsampled_wide_cohorts_vs_oracle(device, oracle, p, rate):
     for a, b in zip(est, est_o):
         np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8)
     assert trace[:, 0].min() >= 0 and trace[:, 0].max() <= (12 if rate != 150 else 34)
+
+
+def test_downsample_hint_only_changes_the_kernel_family(device, oracle):
+    """dn_set_downsample_hint routes a down-sampled p = 10 data set to the row-wise kernels; results are the same."""
+    from degnorm_amd import _lib
+    rng = np.random.default_rng(77)
+    p, rate = 10, 400
+    covs = [synth.synth_gene(12, g, p, rate + 1, 10 * rate)[0] for g in range(80)]
+    offs = rng.integers(0, rate, size=len(covs)).astype(np.int64)
+    scale = np.linspace(0.9, 1.1, p)
+    out = []
+    for hint in (1, rate):
+        dev = _lib.Device(0)
+        dev.hint_downsample(hint)
+        dev.upload(covs)
+        rho, flags, trace = dev.baseline_iteration(scale, nmf_iter=25, min_high_coverage=2, downsample_rate=rate, ds_start=offs)
+        out.append((rho, flags, trace, dev.class_kernel_name(0)))
+        dev.close()
+    assert out[0][3].startswith('k_baseline<10') and out[1][3] == 'k_baseline_gen'
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2][:, [0, 1, 2, 3, 5, 6]], out[1][2][:, [0, 1, 2, 3, 5, 6]])
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-9, atol=1e-11)
+    prm = oracle.make_params(nmf_iter=25, min_high_coverage=2, downsample_rate=rate)
+    rho_o = oracle.baseline_batch(covs, scale, prm, ds_start=offs)[0]
+    np.testing.assert_allclose(out[1][0], rho_o, rtol=1e-8, atol=1e-10)

@@ -8,6 +8,8 @@ from degnorm_amd.nmf_mpi import ShardedNMFOA
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 cfg = dict(synth.CONFIGS['c4'])
+if len(sys.argv) > 2:
+    cfg['p'] = int(sys.argv[2])                 # other cohort sizes in the same down-sampled regime
 t0 = time.time()
 packed, lengths, reads, _ = synth.synth_packed(cfg['seed'], range(n), cfg['p'], cfg['l_min'], cfg['l_max'], n_threads=16)
 print('synthetic slice: %d genes x %d samples, %.2f GB fp32, generated in %.1f s' % (n, cfg['p'], packed.nbytes / 1e9, time.time() - t0))
