@@ -167,13 +167,15 @@ __device__ __attribute__((noinline)) void nmf_gen(const float *Fb, double *A, do
 // and MFMA squaring solver as the templated kernels, with no barrier inside the loop: ~2 us per inner iteration.
 // K E = (A v) v^T, so u_s sigma = a_s . v.  Same outputs as nmf_gen.  The other waves of the workgroup wait.
 // ---------------------------------------------------------------------------------------------------
-constexpr int NSM = 12;
-constexpr int NGS = NSM * (NSM + 1) / 2;      // 78 packed Gram entries
+constexpr int NSM_MAX = 12;                   // widest active matrix the row-wise routine takes
 constexpr int ROWS_ZSLOT = 255;               // last double of g_sm.xw, kept at 0.0 (padding lanes of the solver read it)
 
+// NSM: compiled column capacity (4, 8 or 12: the Gram matrix and the solver's tile shrink with it)
+template <int NSM>
 __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, double *sv, double *sj,
                                                    int n, int S, int T, int first_i, int p)
 {
+    constexpr int NGS = NSM * (NSM + 1) / 2;  // packed Gram entries: 10, 36, 78
     const bool first = first_i != 0;
     if (wave_id() == 0) {
         const int lane = lane_id();
@@ -210,18 +212,7 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             for (int i = 0; i < NSM; i++)
 #pragma unroll
                 for (int j = 0; j <= i; j++) C[i * (i + 1) / 2 + j] = a[i] * a[j];
-            {
-                double lo[64], hi[NGS - 64];
-#pragma unroll
-                for (int i = 0; i < 64; i++) lo[i] = C[i];
-#pragma unroll
-                for (int i = 64; i < NGS; i++) hi[i - 64] = C[i];
-                const int e = reduce_scatter_entry(lane);
-                const double s0 = wave_reduce_scatter<64, double>(lo, lane);
-                const double s1 = wave_reduce_scatter<NGS - 64, double>(hi, lane);
-                tot[e] = s0;
-                if (e < NGS - 64) tot[64 + e] = s1;
-            }
+            wave_round_store<NGS, 0, double>(C, tot, lane, 0.0, tot, false);      // ceil(NGS / 64) reduce-scatter rounds
             wave_fence();
             double tr = 0.0;
 #pragma unroll
@@ -389,7 +380,9 @@ __global__ __launch_bounds__(NT, 2) void k_baseline_gen(IterArgs A)      // two 
                 int csize = 1, n_bins = 0;
                 bool first = true, in_loop = false;
                 for (;;) {
-                    if (n <= NSM) nmf_rows(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    if (n <= 4) nmf_rows<4>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    else if (n <= 8) nmf_rows<8>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    else if (n <= NSM_MAX) nmf_rows<12>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
                     else nmf_gen(Fb, Ast, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
                     if (g_st.status != ST_OK) { status = g_st.status; break; }
                     n_calls++; sum_cols += n;
