@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'obj')
 LIB = os.path.join(HERE, 'libdegnorm_amd.so')
-P_LIST = list(range(2, int(os.environ.get('DN_P_MAX_TEMPLATED', 32)) + 1))   # keep in sync with DN_FOR_EACH_P in csrc/dn_api.hip
+P_LIST = list(range(2, int(os.environ.get('DN_P_MAX_TEMPLATED', 64)) + 1))   # keep in sync with DN_FOR_EACH_P in csrc/dn_api.hip
 ARCH = 'gfx950'
 WIDE_NT = int(os.environ.get('DN_WIDE_NT', 256))     # wide-class workgroup size (csrc/dn_api.hip DN_WIDE_NT)
 NT_LIST = (WIDE_NT, 128)

@@ -16,7 +16,7 @@
 
 // sample counts with compiled kernels (dn_inst.hip is built once per entry; keep in sync with build.py)
 #ifndef DN_P_MAX_TEMPLATED
-#define DN_P_MAX_TEMPLATED 32        // templated kernels for 2 .. this many samples (build.py compiles the same list)
+#define DN_P_MAX_TEMPLATED 64        // templated kernels for 2 .. this many samples (build.py compiles the same list)
 #endif
 #define DN_P_2_16(X)  X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 #define DN_P_17_24(X) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)

@@ -1035,7 +1035,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         if (first) sv[k] = s;
     }
     block_sum_lds<2 * P + 1, P, NT, double>(acc, sm);
-    if (tid < 2 * P + 1) g_gs.sums[tid] = sm.tot[tid];
+    for (int e = tid; e < 2 * P + 1; e += NT) g_gs.sums[e] = sm.tot[e];      // 2 p + 1 can exceed the workgroup (p = 64, 128 threads)
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < P; i++) g_gs.u[i] = u[i];

@@ -232,9 +232,9 @@ def test_full_size_head_vs_oracle(device, oracle):
     np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
 
 
-@pytest.mark.parametrize('p', [2, 3, 7, 12, 13, 14, 16, 17, 20, 24, 31, 32, 33, 40])
+@pytest.mark.parametrize('p', [2, 3, 7, 12, 13, 14, 16, 17, 20, 24, 31, 32, 33, 40, 48, 49, 64])
 def test_sample_counts_and_edge_shapes_vs_oracle(device, oracle, p):
-    """Every compiled sample count family (templated 2..32: one / several Gram sweeps, MFMA / row solver; run-time-p above)
+    """Every compiled sample count family (templated 2..48: one / several Gram sweeps, MFMA / row solver; run-time-p above)
     on ragged / tiny / single-gene inputs."""
     rng = np.random.default_rng(100 + p)
     covs = [synth.synth_gene(9, g, p, 60, 900)[0] for g in range(10)]
@@ -400,7 +400,7 @@ def test_many_small_ragged_genes_vs_oracle(device, oracle, p):
 
 
 @pytest.mark.parametrize('p,rate', [(13, 100), (50, 500), (64, 250), (50, 150)])
-def test_downsampled_wide_cohorts_vs_oracle(device, oracle, p, rate):
+def test_downsampled_wide_cohorts_vs_oracle(oracle, p, rate, monkeypatch):
     """
     The row-wise nmf of the run-time-p kernels (dn_generic.hip, nmf_rows: active matrices of <= 12 columns, one wave per
     gene) and its hand-over to the block-wide path: with take-every `rate` the genes below have 2 .. 12 active columns,
@@ -419,7 +419,13 @@ def test_downsampled_wide_cohorts_vs_oracle(device, oracle, p, rate):
         offs.append(int(rng.integers(0, rate)))
     offs = np.asarray(offs, dtype=np.int64)
     scale = np.linspace(0.9, 1.1, p)
+    from degnorm_amd import _lib
+    if rate == 150:
+        monkeypatch.setenv('DN_FORCE_GENERIC', '1')      # up to 33 active columns: nmf_rows and the block-wide nmf_gen side by side
+    device = _lib.Device(0)
+    device.hint_downsample(rate)                         # <= 12 active columns per gene: the library picks the row-wise kernels
     device.upload(covs)
+    assert device.class_kernel_name(0) == 'k_baseline_gen'
     rho, flags, trace = device.baseline_iteration(scale, nmf_iter=30, min_high_coverage=2, downsample_rate=rate,
                                                   ds_start=offs, want_estimates=True)
     prm = oracle.make_params(nmf_iter=30, min_high_coverage=2, downsample_rate=rate)
@@ -431,6 +437,7 @@ def test_downsampled_wide_cohorts_vs_oracle(device, oracle, p, rate):
     for a, b in zip(est, est_o):
         np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8)
     assert trace[:, 0].min() >= 0 and trace[:, 0].max() <= (12 if rate != 150 else 34)
+    device.close()
 
 
 def test_downsample_hint_only_changes_the_kernel_family(device, oracle):
