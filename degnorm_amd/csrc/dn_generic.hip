@@ -1,5 +1,5 @@
 // dn_generic.hip -- run-time-p variants of the kernels for sample counts above the register-resident range
-// (32 < p <= 64; BASELINE config 4 is p = 50 with take-every 500, active matrices 50 x <= 10).
+// (any p <= 64; BASELINE config 4 is p = 50 with take-every 500, active matrices 50 x <= 10).
 //
 // Same state machine and outputs as k_baseline<P,...> (dn_kernels.hpp; reference nmf.py:189-372), but the
 // p x p Gram matrix no longer fits in registers, so the top singular vector of x + lambda is found by power

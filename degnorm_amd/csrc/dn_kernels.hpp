@@ -51,7 +51,7 @@ namespace dn {
 
 constexpr int TRACE_LEN = 48;
 constexpr int MAX_BINS = 64;
-constexpr int P_MAX = 64;      // largest sample count any kernel accepts (templated kernels: <= 32; generic: <= 64)
+constexpr int P_MAX = 64;      // largest sample count any kernel accepts (templated and run-time-p kernels alike)
 
 enum { EXIT_LOW_COV = 0, EXIT_ZERO_SAMPLE = 1, EXIT_MEDIAN = 2, EXIT_NO_LOOP = 3,
        EXIT_REFINED = 4, EXIT_REFINE_FALLBACK = 5, EXIT_NOT_FOUND_FALLBACK = 6 };
@@ -1504,6 +1504,6 @@ struct KernelSet {
 };
 
 const KernelSet *kernel_set_for(int p);   // dn_api.hip
-const KernelSet *kernel_set_generic();    // dn_generic.hip (run-time p, 32 < p <= P_MAX)
+const KernelSet *kernel_set_generic();    // dn_generic.hip (run-time p, any p <= P_MAX)
 
 }  // namespace dn
