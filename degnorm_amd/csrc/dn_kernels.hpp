@@ -124,15 +124,25 @@ struct EstArgs {
 // ---------------------------------------------------------------------------------------------------
 // LDS layout of one workgroup (static part; the lambda tile is dynamic shared memory behind it).
 // ---------------------------------------------------------------------------------------------------
+// From this sample count on the Gram matrix is accumulated by the fp64 matrix cores (mg_core below) instead of in
+// per-lane registers swept several times over the state.
+#ifndef DN_MG_MIN_P
+#define DN_MG_MIN_P 25
+#endif
+
 template <int P, int NT>
 struct Smem {
     static constexpr int W = NT / 64;
+    static constexpr int MG_TR = (P + 15) / 16;                 // 16-row tiles covering the samples
+    static constexpr int MG_STR = 16 * MG_TR;                   // doubles per staged column (zero-padded rows)
     static constexpr int NG = P * (P + 1) / 2;
     static constexpr int NX = NG >= 64 ? NG + 2 : 64;
     static constexpr int ZSLOT = NX - 1;     // tot[ZSLOT] is written once (0.0): the load target of padding lanes
     double xw[W][NX];                        // per-wave totals (cross-wave combine)
     double tot[NX];                          // block totals (broadcast)
     double dsel[NX];                         // 1.0 at the packed indices of the Gram diagonal, else 0.0
+    double stage[P >= DN_MG_MIN_P ? W * 16 * MG_STR : 2];      // per wave: 16 updated columns in the MFMA operand layout
+    double eigv[P >= DN_MG_MIN_P ? W * 2 * 64 : 2];            // per wave: current eigenvector u and a work vector
     double ss[MAX_BINS];                     // per-bin mean squared residual
     int32_t alive[MAX_BINS];                 // original ids of the surviving bins, in order
     int32_t cnt[W];                          // per-wave hi-coverage counts
@@ -568,6 +578,80 @@ __device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], d
     return steps + 1;
 }
 
+// The same iteration for wide cohorts: lane l keeps row l of G in registers (p doubles) and ITS component of the
+// vectors; the vectors live in wave-private LDS (uv: current eigenvector, warm start of the next solve; vv: work vector)
+// and are read back with broadcast loads, so nothing of size p sits in registers besides the row.  Norms and the
+// Rayleigh quotient are all-reduced over the 64 lanes in registers (identical bits in every lane).
+__device__ __forceinline__ double wave_allsum(double v)
+{
+    v += dpp_mov<DPP_QX1>(v);
+    v += dpp_mov<DPP_QX2>(v);
+    v += dpp_mov<0x141>(v);          // row_half_mirror
+    v += dpp_mov<0x140>(v);          // row_mirror
+    return allsum_rows(v);
+}
+
+template <int P>
+__device__ __forceinline__ double lds_row_dot(const double (&Gr)[P], const double *vec)
+{
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j + 1 < P; j += 2) {
+        const double2 v2 = *reinterpret_cast<const double2 *>(vec + j);
+        a0 = fma(Gr[j], v2.x, a0); a1 = fma(Gr[j + 1], v2.y, a1);
+    }
+    if (P & 1) a0 = fma(Gr[P - 1], vec[P - 1], a0);
+    return a0 + a1;
+}
+
+template <int P>
+__device__ __forceinline__ int top_eig_rows_lds(const double *tot, double *uv, double *vv, double &theta)
+{
+    static_assert(P <= 64, "one row per lane");
+    const int lane = lane_id();
+    const bool live = lane < P;
+    const int r = live ? lane : P - 1;
+    double Gr[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const int a = r > j ? r : j, b = r > j ? j : r;
+        Gr[j] = live ? tot[a * (a + 1) / 2 + b] : 0.0;
+    }
+    const double tr = wave_allsum(live ? tot[r * (r + 1) / 2 + r] : 0.0);
+    double ul = live ? uv[r] : 0.0;
+    double y = lds_row_dot<P>(Gr, uv);                                  // (G u)_l
+    double th = wave_allsum(ul * y);
+    if (!(th > 0.0)) { theta = 0.0; return 1; }
+    double mu = (tr - th) * (1.0 / (double) (P > 1 ? P - 1 : 1));
+    mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
+    double vl = fma(-mu, ul, y);                                        // first shifted step
+    int steps = 1;
+    double d2_prev = -1.0;
+    for (;;) {
+        const double n2 = wave_allsum(vl * vl);
+        if (!(n2 > 0.0)) { theta = 0.0; return steps; }
+        const double inv = rsqrt_newton(n2);
+        const double un = vl * inv;
+        const double d = un - ul;
+        const double d2 = wave_allsum(d * d);
+        ul = un;
+        wave_fence();
+        if (live) uv[r] = ul;
+        wave_fence();
+        if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev) || steps >= 4000) break;
+        d2_prev = d2;
+        const double wl = fma(-mu, ul, lds_row_dot<P>(Gr, uv));        // two plain shifted steps, no normalisation in between
+        if (live) vv[r] = wl;
+        wave_fence();
+        vl = fma(-mu, wl, lds_row_dot<P>(Gr, vv));
+        wave_fence();
+        steps += 2;
+    }
+    y = lds_row_dot<P>(Gr, uv);                                         // Rayleigh quotient of the unshifted matrix
+    theta = wave_allsum(ul * y);
+    return steps + 1;
+}
+
 // One interface over the two solvers: the MFMA squaring solver with its carried state for p <= 16, the row-distributed
 // power iteration above it.
 template <int P, bool MFMA = (P <= 16)> struct Solver;
@@ -727,6 +811,27 @@ __device__ __forceinline__ void col_update(const double (&f)[P], double (&a)[P],
     }
 }
 
+// Wide cohorts: u and 1/s come from LDS (broadcast loads) and F = x / s is formed element by element, so that next to
+// the state only the raw counts of the column are live (at p = 64: 128 + 64 registers instead of 4 x 128).
+template <int P>
+__device__ __forceinline__ void col_update_lds(const float (&x)[P], const double *invp, double (&a)[P], const double *uv, double c)
+{
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i + 1 < P; i += 2) {
+        const double2 u2 = *reinterpret_cast<const double2 *>(uv + i);
+        s0 = fma(u2.x, a[i], s0); s1 = fma(u2.y, a[i + 1], s1);
+    }
+    if (P & 1) s0 = fma(uv[P - 1], a[P - 1], s0);
+    const double s = s0 + s1;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const double fi = (double) x[i] * invp[i];
+        const double res = fma(uv[i], s, -fi);
+        a[i] = fmax(fma(-c, res, a[i]), fi);
+    }
+}
+
 template <int P>
 __device__ __forceinline__ void col_final(const double (&f)[P], const double (&a)[P], const double (&u)[P], bool first,
                                           double (&acc)[2 * P + 1], double &s_out, double &r_out)
@@ -807,6 +912,169 @@ __device__ __forceinline__ gdouble_ptr spill_ptr(gdouble_ptr Lg, int k)
     return Lg + ((size_t) (k >> 6) * (64 * P) + (size_t) (k & 63));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wide cohorts (p >= DN_MG_MIN_P): cold start and the T inner iterations of one nmf() call with the Gram matrix on the
+// matrix cores.  A per-lane register Gram needs p (p + 1) / 2 accumulators and, beyond ~100 of them, several sweeps over
+// the state; a 16 x 16 fp64 MFMA tile needs 8 registers, so all (p / 16)^2 / 2 tiles of the matrix stay resident and ONE
+// pass per inner iteration is enough.  fp64 MFMA runs at the fp64 vector rate on gfx950 (and does not overlap with it),
+// so the arithmetic costs the same; what goes away is the re-reading of the state, the AGPR traffic of the accumulators
+// and the per-wave reduce-scatter (an MFMA sums over the 64 columns of a wave by itself).
+// Every wave walks its 64-column steps in lock-step: each lane updates its column as in the narrow-cohort kernels, the
+// updated columns are staged 16 at a time in LDS (zero-padded to 16 x MG_TR rows), re-read in the operand layout
+// (lane (i = l & 15, kq = l >> 4) <- row 16 tr + i of staged column 4 g + kq) and multiplied tile row by tile row:
+// D[tr1][tr2] += X[tr1] X[tr2]^T over four columns per instruction.
+// ---------------------------------------------------------------------------------------------------
+template <int P, int NT>
+__device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, int n, int nL, int T,
+                                       double (&u)[P], double &theta, int &steps)
+{
+    constexpr int W = NT / 64;
+    constexpr int NG = P * (P + 1) / 2;
+    constexpr int PS = P + (P & 1);
+    constexpr int TR = Smem<P, NT>::MG_TR, STR = Smem<P, NT>::MG_STR;
+    constexpr int NTILE = TR * (TR + 1) / 2;
+    Smem<P, NT> &sm = g_sm;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int nLe = (n < nL) ? n : nL;
+    double *stage = &sm.stage[w * 16 * STR];
+    double *uv = &sm.eigv[w * 128], *vv = uv + 64;                     // this wave's copy of u and a work vector
+    const double *invp = g_gs.inv;
+    for (int e = lane; e < 16 * STR; e += 64) stage[e] = 0.0;          // rows >= p of a staged column stay zero
+    uv[lane] = lane < P ? 1.0 / sqrt((double) P) : 0.0;                // cold start of the solver
+    vv[lane] = 0.0;
+    wave_fence();
+    const int oi = lane & 15, okq = lane >> 4;
+    dn_double4 acc[NTILE];
+
+    auto feed = [&](const double (&a)[PS], bool valid) {
+#pragma unroll
+        for (int cq = 0; cq < 4; cq++) {
+            if ((lane >> 4) == cq) {
+                double *dst = stage + (lane & 15) * STR;
+#pragma unroll
+                for (int i = 0; i < PS; i += 2) *reinterpret_cast<double2 *>(dst + i) = make_double2(valid ? a[i] : 0.0, valid ? a[i + 1] : 0.0);
+            }
+            wave_fence();
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                double x[TR];
+#pragma unroll
+                for (int tr = 0; tr < TR; tr++) x[tr] = stage[(4 * g + okq) * STR + 16 * tr + oi];
+                int tix = 0;
+#pragma unroll
+                for (int t1 = 0; t1 < TR; t1++)
+#pragma unroll
+                    for (int t2 = 0; t2 <= t1; t2++, tix++)
+                        acc[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[t1], x[t2], acc[tix], 0, 0, 0);
+            }
+            wave_fence();
+        }
+    };
+
+    const double c = 1.0 / sqrt((double) T);                           // nmf.py:91
+    // one pass over the active columns: cold (a = F, Gram of F: nmf.py:88) or inner iteration t (nmf.py:93-99)
+    auto pass = [&](bool cold, int t) {
+#pragma unroll
+        for (int i = 0; i < NTILE; i++) acc[i] = dn_double4{0.0, 0.0, 0.0, 0.0};
+        const int wb = w * 64;
+        const int steps_l = wb < nLe ? (nLe - wb + NT - 1) / NT : 0;    // wave-uniform trip counts
+        const int steps_s = nL + wb < n ? (n - nL - wb + NT - 1) / NT : 0;
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < steps_l; j++) {
+            const int k = tid + j * NT;
+            const bool valid = k < nLe;
+            double a[PS];
+#pragma unroll
+            for (int i = 0; i < PS; i++) a[i] = 0.0;
+            if (valid) {
+                float xr[P];
+                load_x<P>(Fb, k, xr);
+                if (cold) {
+#pragma unroll
+                    for (int i = 0; i < P; i++) a[i] = (double) xr[i] * invp[i];
+                } else {
+                    double al[PS], aa[P];
+                    lds_col_read<PS>(lam + (size_t) k * PS, al);
+#pragma unroll
+                    for (int i = 0; i < P; i++) aa[i] = al[i];
+                    col_update_lds<P>(xr, invp, aa, uv, c);
+#pragma unroll
+                    for (int i = 0; i < P; i++) a[i] = aa[i];
+                }
+                lds_col_write<PS>(lam + (size_t) k * PS, a);            // lmbda = zeros on the cold pass: state a = x
+            }
+            feed(a, valid);
+        }
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < steps_s; j++) {
+            const int k = nL + tid + j * NT;
+            const bool valid = k < n;
+            double a[PS];
+#pragma unroll
+            for (int i = 0; i < PS; i++) a[i] = 0.0;
+            if (valid) {
+                float xr[P];
+                double aa[P];
+                load_x<P>(Fb, k, xr);
+                if (cold || t == 0) {
+#pragma unroll
+                    for (int i = 0; i < P; i++) aa[i] = (double) xr[i] * invp[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < P; i++) aa[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
+                }
+                if (!cold) {
+                    col_update_lds<P>(xr, invp, aa, uv, c);
+#pragma unroll
+                    for (int i = 0; i < P; i++) DN_SPILL_STORE(aa[i], spill_ptr<P>(Lg, k) + i * 64);
+                }
+#pragma unroll
+                for (int i = 0; i < P; i++) a[i] = aa[i];
+            }
+            feed(a, valid);
+        }
+        // tile (t1, t2), register r of lane (c = l & 15, q = l >> 4) holds G[16 t1 + q + 4 r][16 t2 + c]: this wave's
+        // totals go to xw, the cross-wave add packs them into tot
+        {
+            double *dst = (W > 1) ? sm.xw[w] : sm.tot;
+            int tix = 0;
+#pragma unroll
+            for (int t1 = 0; t1 < TR; t1++)
+#pragma unroll
+                for (int t2 = 0; t2 <= t1; t2++, tix++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * t1 + okq + 4 * r, col = 16 * t2 + oi;
+                        if (row < P && col <= row) dst[row * (row + 1) / 2 + col] = acc[tix][r];
+                    }
+        }
+        if constexpr (W > 1) {
+            __syncthreads();
+            for (int e = tid; e < NG; e += NT) {
+                double tsum = sm.xw[0][e];
+#pragma unroll
+                for (int ww = 1; ww < W; ww++) tsum += sm.xw[ww][e];
+                sm.tot[e] = tsum;
+            }
+        }
+        __syncthreads();
+    };
+
+    pass(true, 0);
+    {
+        const double tr = wave_allsum(lane < P ? sm.tot[lane * (lane + 1) / 2 + lane] : 0.0);
+        if (!(tr > 0.0)) return ST_ARPACK;
+    }
+    steps += top_eig_rows_lds<P>(sm.tot, uv, vv, theta);
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < T; t++) {
+        pass(false, t);
+        steps += top_eig_rows_lds<P>(sm.tot, uv, vv, theta);
+    }
+    bcast_rows<P>(lane < P ? uv[lane] : 0.0, u);                        // the final pass wants u as a uniform array
+    return ST_OK;
+}
+
 // Out of line on purpose: the call has its own register allocation (Gram accumulators + one column in
 // flight), independent of what the state machine keeps live, so that two waves fit on a SIMD.
 template <int P, int NT>
@@ -850,6 +1118,10 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
     const int tid = threadIdx.x;
     const int nLe = (n < nL) ? n : nL;                     // end of the LDS tier
+    if constexpr (P >= DN_MG_MIN_P) {
+        const int st = mg_core<P, NT>(Fb, Lg, lam, n, nL, T, u, theta, steps);
+        if (st != ST_OK) { if (tid == 0) g_gs.status = st; __syncthreads(); return; }
+    } else {
     gram_t G[CH];
 
     // cold start: SVD of x itself (nmf.py:88)
@@ -1012,6 +1284,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
         DN_T1(2); }
     }
+    }   // narrow cohorts
 
     // final pass: K E of the last SVD, its row sums, the clamped row sums and the residual profile.
     double acc[2 * P + 1];
