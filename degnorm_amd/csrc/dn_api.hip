@@ -290,6 +290,7 @@ static int finish_upload(dn_handle h, const float *host_packed)
             h->split_len = (int32_t) std::max<int64_t>(0, (int64_t) (2.1 * (double) (lds_n / (8 * (int64_t) (p + (p & 1))))));
         }
         if (!narrow) h->split_len = 0;
+        if (!env && p >= 25) h->split_len = 0;     // wide cohorts (MFMA Gram): one class measured 3-5 % faster than two
         std::vector<int32_t> ord[2];
         for (int32_t g : order) ord[(h->split_len > 0 && h->glen[g] <= h->split_len) ? 1 : 0].push_back(g);   // stays longest-first
         h->cls[0].ks = h->ks;
