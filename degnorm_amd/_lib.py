@@ -53,6 +53,7 @@ def load(build_if_missing=False):
     lib.dn_upload_ragged.argtypes = [vp, i64, i32, P(vp), P(i64), i32, i32, P(i64)]
     lib.dn_upload_packed.argtypes = [vp, i64, i32, P(c.c_float), P(i64)]
     lib.dn_set_downsample_hint.argtypes = [vp, i32]
+    lib.dn_set_solver_step_cap.argtypes = [vp, i32]
     lib.dn_ratio_svd_sums.argtypes = [vp, P(dbl), P(dbl), P(i32)]
     lib.dn_baseline_iteration.argtypes = [vp, P(dbl), P(Params), P(i64), P(dbl), P(i32), P(i32)]
     lib.dn_fetch_estimates.argtypes = [vp, P(dbl)]
@@ -122,6 +123,11 @@ class Device:
     def hint_downsample(self, rate):
         """Announce the take-every rate before an upload (kernel-family choice only; see dn_set_downsample_hint)."""
         _check(self.lib.dn_set_downsample_hint(self.h, int(max(1, rate))))
+        return self
+
+    def set_solver_step_cap(self, max_steps):
+        """Step cap of one on-chip eigen-solve (default 4000); genes that hit it get per-gene status -4."""
+        _check(self.lib.dn_set_solver_step_cap(self.h, int(max_steps)))
         return self
 
     def upload(self, cov_mats, n_threads=0):
@@ -204,11 +210,16 @@ class Device:
             o += cnt
         return [mats[k] for k in inverse]
 
-    def fetch_estimates(self):
-        """List of (p x L_g) float64 arrays, views into one flat buffer, in upload order."""
+    def fetch_estimates_flat(self):
+        """All estimates in one float64 buffer: gene g at p * sum(lengths[:g]), p x L_g row-major."""
         total = int(self.lengths.sum()) * self.p
         flat = np.empty(total, dtype=np.float64)
         _check(self.lib.dn_fetch_estimates(self.h, _p(flat, ctypes.c_double)))
+        return flat
+
+    def fetch_estimates(self):
+        """List of (p x L_g) float64 arrays, views into one flat buffer, in upload order."""
+        flat = self.fetch_estimates_flat()
         out, o = [], 0
         for L in self.lengths:
             cnt = self.p * int(L)

@@ -64,10 +64,11 @@ def build_library(force=False, verbose=False):
             if force or _newer(o, [inst] + hdr):
                 jobs.append([hipcc] + FLAGS + SCHED + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt), '-c', inst, '-o', o])
     gen = os.path.join(CSRC, 'dn_generic.hip')
-    o_gen = os.path.join(OBJ, 'dn_generic.o')
-    objs.append(o_gen)
-    if force or _newer(o_gen, [gen] + hdr):
-        jobs.append([hipcc] + FLAGS + ['-c', gen, '-o', o_gen])
+    for gnt in (256, 64):       # general run-time-p family / one-wavefront-per-gene family (down-sampled regime)
+        o_gen = os.path.join(OBJ, 'dn_generic_nt{0}.o'.format(gnt))
+        objs.append(o_gen)
+        if force or _newer(o_gen, [gen] + hdr):
+            jobs.append([hipcc] + FLAGS + EXTRA + ['-DDN_GEN_NT={0}'.format(gnt), '-c', gen, '-o', o_gen])
     asm = os.path.join(CSRC, 'dn_assemble.hip')
     o_asm = os.path.join(OBJ, 'dn_assemble.o')
     objs.append(o_asm)

@@ -59,6 +59,8 @@ const KernelSet *kernel_set_narrow(int p)
     }
 }
 
+const KernelSet *kernel_set_rows();       // dn_generic.hip compiled with DN_GEN_NT=64: one wavefront per gene
+
 const KernelSet *kernel_set_for(int p)
 {
     // DN_FORCE_GENERIC=1 routes every supported p through the run-time-p kernels (used by the tests to
@@ -73,6 +75,26 @@ const KernelSet *kernel_set_for(int p)
     }
 }
 }  // namespace dn
+
+// Row maxima of the raw coverage, once per upload: max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i) for s_i > 0, so the
+// 0.1 * max(F) threshold of get_high_coverage_idx (nmf.py:66-76) needs these p numbers per gene instead of a scan of
+// the whole scaled matrix in every outer iteration (SURVEY 8(d), config-4 regime note).  One workgroup per gene.
+__global__ __launch_bounds__(256) void k_row_max(const float *__restrict__ cov, const int64_t *__restrict__ goff,
+                                                 const int32_t *__restrict__ glen, float *__restrict__ rowmax, int n, int p)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int g = blockIdx.x; g < n; g += gridDim.x) {
+        const int L = glen[g];
+        for (int i = w; i < p; i += 4) {
+            const float *row = cov + goff[g] + (size_t) i * L;
+            float m = row[0];
+            for (int j = lane; j < L; j += 64) m = fmaxf(m, row[j]);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) rowmax[(size_t) g * p + i] = m;
+        }
+    }
+}
 
 static thread_local std::string g_err;
 
@@ -114,6 +136,7 @@ struct dn_handle_s {
     int32_t *d_emode = nullptr;
     double  *d_svec = nullptr;
     int64_t *d_svoff = nullptr;
+    float   *d_rowmax = nullptr;      // n x p row maxima of the raw coverage (k_row_max at upload)
     double  *d_est_sums = nullptr, *d_cov_sums = nullptr;
     int32_t *d_status = nullptr;
     double  *d_est = nullptr;
@@ -127,6 +150,7 @@ struct dn_handle_s {
     struct GeneClass {
         const dn::KernelSet *ks = nullptr;
         int32_t n = 0;
+        int32_t longest = 0;              // longest gene of the class
         int32_t *d_order = nullptr;
         std::vector<int32_t> order;       // host copy of the work queue (gene ids)
         int32_t *d_counter = nullptr;
@@ -149,6 +173,7 @@ struct dn_handle_s {
     bool have_estimate_state = false;
     float last_ms = 0.f;
     int32_t ds_hint = 1;          // take-every rate the caller intends to use (dn_set_downsample_hint); 1 = none
+    int32_t max_steps = dn::EIG_MAX_STEPS_DEFAULT;   // step cap of one eigen-solve (dn_set_solver_step_cap)
     // per-gene counters of the previous dn_baseline_iteration: the narrow class orders its queue by the work they predict
     std::vector<int32_t> host_trace;
     bool have_trace = false;
@@ -159,7 +184,7 @@ static void free_device(dn_handle h)
 {
     void *ptrs[] = {h->d_cov, h->d_goff, h->d_glen, h->d_order, h->d_counter, h->d_ds, h->d_ws, h->d_rho, h->d_flags,
                     h->d_trace, h->d_kfin, h->d_emode, h->d_svec, h->d_svoff, h->d_est_sums, h->d_cov_sums,
-                    h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col};
+                    h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col, h->d_rowmax};
     for (void *q : ptrs) if (q && q != (void *) h->cls[0].d_ws) (void) hipFree(q);
     for (auto &c : h->cls) {
         if (c.d_order) (void) hipFree(c.d_order);
@@ -171,6 +196,7 @@ static void free_device(dn_handle h)
     h->d_ds = nullptr; h->d_ws = nullptr; h->d_rho = nullptr; h->d_flags = nullptr; h->d_trace = nullptr;
     h->d_kfin = nullptr; h->d_emode = nullptr; h->d_svec = nullptr; h->d_svoff = nullptr; h->d_est_sums = nullptr;
     h->d_cov_sums = nullptr; h->d_status = nullptr; h->d_est = nullptr; h->d_tile_gene = nullptr; h->d_tile_col = nullptr;
+    h->d_rowmax = nullptr;
     h->have_estimate_state = false;
 }
 
@@ -188,9 +214,22 @@ int dn_device_count(void)
 
 int dn_p_supported(int p) { return dn::kernel_set_for(p) != nullptr; }
 
+static int create_streams(dn_handle h)
+{
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev2a));
+    HIP_TRY(hipEventCreate(&h->ev2b));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    return DN_OK;
+}
+
 int dn_create(int device, dn_handle *out)
 {
     if (!out) return fail(DN_E_INVALID, "dn_create: out is null");
+    *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DN_E_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(DN_E_INVALID, "dn_create: device index out of range");
@@ -200,13 +239,12 @@ int dn_create(int device, dn_handle *out)
     dn_handle h = new dn_handle_s();
     h->device = device;
     h->n_cus = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&h->ev0));
-    HIP_TRY(hipEventCreate(&h->ev1));
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&h->ev2a));
-    HIP_TRY(hipEventCreate(&h->ev2b));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    const int rc = create_streams(h);
+    if (rc != DN_OK) {                       // nothing leaks: dn_destroy releases whatever was created
+        const std::string msg = g_err;
+        (void) dn_destroy(h);
+        return fail(rc, msg);
+    }
     *out = h;
     return DN_OK;
 }
@@ -215,7 +253,7 @@ int dn_destroy(dn_handle h)
 {
     if (!h) return DN_OK;
     (void) hipSetDevice(h->device);
-    (void) hipStreamSynchronize(h->stream);
+    if (h->stream) (void) hipStreamSynchronize(h->stream);
     free_device(h);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
@@ -228,7 +266,38 @@ int dn_destroy(dn_handle h)
     return DN_OK;
 }
 
-static int finish_upload(dn_handle h, const float *host_packed)
+// Scratch slots and LDS tier of one gene class for genes of up to `cols` active columns.
+static int size_class(dn_handle h, dn_handle_s::GeneClass &C, int32_t cols)
+{
+    const int32_t p = h->p;
+    if (C.d_ws) { (void) hipFree(C.d_ws); C.d_ws = nullptr; }
+    int per_cu = C.ks->blocks_per_cu(0);
+    if (per_cu < 1) per_cu = 1;
+    C.slots = (int) std::min<int64_t>(C.n, (int64_t) per_cu * h->n_cus);
+    C.S = (cols + 63) & ~63;
+    // slot: Fs, Fb (fp32, p x S) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
+    C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double));
+    {
+        // one very long gene sizes every slot of its class: keep the scratch within a share of free HBM by
+        // running fewer persistent workgroups rather than failing
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const int64_t budget = (int64_t) (free_b / 3);
+        if (C.slot_bytes > budget) return fail(DN_E_INVALID, "a gene is too long for the device scratch (" + std::to_string(C.S) + " columns)");
+        C.slots = (int) std::max<int64_t>(1, std::min<int64_t>(C.slots, budget / C.slot_bytes));
+    }
+    HIP_TRY(hipMalloc(&C.d_ws, (size_t) C.slot_bytes * (size_t) std::max(C.slots, 1)));
+    // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
+    const int64_t lds_per_block = (160 * 1024) / per_cu - (int64_t) C.ks->static_lds_bytes - 256;
+    const int64_t ps = p + (p & 1);                        // LDS column stride in doubles (16-B aligned)
+    int64_t lcols = lds_per_block > 0 ? lds_per_block / (8 * ps) : 0;
+    lcols = std::min<int64_t>(lcols, C.S) & ~(int64_t) 1;
+    C.lds_cols = (int32_t) lcols;
+    C.dyn_lds = (size_t) lcols * 8 * (size_t) ps;
+    return DN_OK;
+}
+
+static int finish_upload_impl(dn_handle h, const float *host_packed)
 {
     const int64_t n = h->n;
     const int32_t p = h->p;
@@ -265,6 +334,7 @@ static int finish_upload(dn_handle h, const float *host_packed)
     HIP_TRY(hipMalloc(&h->d_est_sums, sizeof(double) * (size_t) n * p));
     HIP_TRY(hipMalloc(&h->d_cov_sums, sizeof(double) * (size_t) n * p));
     HIP_TRY(hipMalloc(&h->d_status, sizeof(int32_t) * (size_t) n));
+    HIP_TRY(hipMalloc(&h->d_rowmax, sizeof(float) * (size_t) n * p));
     HIP_TRY(hipMalloc(&h->d_tile_gene, sizeof(int32_t) * (size_t) std::max<int64_t>(h->n_tiles, 1)));
     HIP_TRY(hipMalloc(&h->d_tile_col, sizeof(int32_t) * (size_t) std::max<int64_t>(h->n_tiles, 1)));
 
@@ -275,6 +345,9 @@ static int finish_upload(dn_handle h, const float *host_packed)
     HIP_TRY(hipMemcpyAsync(h->d_svoff, h->svoff.data(), sizeof(int64_t) * (size_t) (n + 1), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_tile_gene, tg.data(), sizeof(int32_t) * tg.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_tile_col, tc.data(), sizeof(int32_t) * tc.size(), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_row_max, dim3((unsigned) std::min<int64_t>(n, (int64_t) h->n_cus * 8)), dim3(256), 0, h->stream,
+                       h->d_cov, h->d_goff, h->d_glen, h->d_rowmax, (int) n, (int) p);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
 
     // gene classes
@@ -323,32 +396,28 @@ static int finish_upload(dn_handle h, const float *host_packed)
             HIP_TRY(hipMalloc(&C.d_counter, sizeof(int32_t) * 4));
             HIP_TRY(hipMemcpy(C.d_order, ord[c].data(), sizeof(int32_t) * (size_t) C.n, hipMemcpyHostToDevice));
             C.order = ord[c];
-            int per_cu = C.ks->blocks_per_cu(0);
-            if (per_cu < 1) per_cu = 1;
-            C.slots = (int) std::min<int64_t>(C.n, (int64_t) per_cu * h->n_cus);
-            C.S = (h->glen[ord[c][0]] + 63) & ~63;                    // longest gene of the class
-            // slot: Fs, Fb (fp32, p x S) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
-            C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double));
-            {
-                // one very long gene sizes every slot of its class: keep the scratch within a share of free HBM by
-                // running fewer persistent workgroups rather than failing
-                size_t free_b = 0, total_b = 0;
-                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-                const int64_t budget = (int64_t) (free_b / 3);
-                if (C.slot_bytes > budget) return fail(DN_E_INVALID, "a gene is too long for the device scratch (" + std::to_string(C.S) + " columns)");
-                C.slots = (int) std::max<int64_t>(1, std::min<int64_t>(C.slots, budget / C.slot_bytes));
-            }
-            HIP_TRY(hipMalloc(&C.d_ws, (size_t) C.slot_bytes * (size_t) std::max(C.slots, 1)));
-            // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
-            const int64_t lds_per_block = (160 * 1024) / per_cu - (int64_t) C.ks->static_lds_bytes - 256;
-            const int64_t ps = p + (p & 1);                        // LDS column stride in doubles (16-B aligned)
-            int64_t cols = lds_per_block > 0 ? lds_per_block / (8 * ps) : 0;
-            cols = std::min<int64_t>(cols, C.S) & ~(int64_t) 1;
-            C.lds_cols = (int32_t) cols;
-            C.dyn_lds = (size_t) cols * 8 * (size_t) ps;
+            // columns a scratch slot must hold: the longest gene of the class, or -- for the one-wave-per-gene family,
+            // chosen because the announced take-every rate leaves every gene at most 12 active columns -- that bound
+            int32_t cols = C.longest = h->glen[ord[c][0]];
+            if (C.ks == dn::kernel_set_rows()) cols = (cols + h->ds_hint - 1) / h->ds_hint;
+            const int rc = size_class(h, C, cols);
+            if (rc != DN_OK) return rc;
         }
         if (h->cls[0].n == 0 && h->cls[1].n > 0 && h->ks->p == 0) return fail(DN_E_STATE, "internal: empty wide class for the generic kernels");
         h->slots = h->cls[0].slots; h->S = h->cls[0].S; h->slot_bytes = h->cls[0].slot_bytes; h->d_ws = h->cls[0].d_ws;
+    }
+    return DN_OK;
+}
+
+// A failed upload leaves the handle EMPTY (no resident coverage, later calls return DN_E_STATE), never half-sized.
+static int finish_upload(dn_handle h, const float *host_packed)
+{
+    const int rc = finish_upload_impl(h, host_packed);
+    if (rc != DN_OK) {
+        const std::string msg = g_err;
+        free_device(h);
+        h->n = 0; h->total = 0;
+        return fail(rc, msg);
     }
     return DN_OK;
 }
@@ -360,24 +429,31 @@ static int check_shape(dn_handle h, int64_t n_genes, int32_t p, const int64_t *l
     if (p < 2) return fail(DN_E_INVALID, "need at least 2 samples (svds(k=1) requires 1 < min(shape), nmf.py:63)");
     const dn::KernelSet *ks = dn::kernel_set_for(p);
     if (!ks) return fail(DN_E_UNSUPPORTED, "no kernels compiled for p = " + std::to_string(p));
-    h->ks = ks;
-    bool rows_regime = h->ds_hint > 1 && p >= 8;
-    h->n = n_genes; h->p = p;
-    h->goff.assign(n_genes + 1, 0);
-    h->glen.assign(n_genes, 0);
+    // validate into locals; the handle is only touched once everything checks out
+    std::vector<int64_t> goff((size_t) n_genes + 1, 0);
+    std::vector<int32_t> glen((size_t) n_genes, 0);
     int32_t lmax = 0;
     for (int64_t g = 0; g < n_genes; g++) {
         if (lengths[g] < 1 || lengths[g] > (int64_t) 1 << 26) return fail(DN_E_INVALID, "gene length out of range at gene " + std::to_string(g));
-        h->glen[g] = (int32_t) lengths[g];
-        h->goff[g + 1] = h->goff[g] + (int64_t) p * lengths[g];
-        lmax = std::max(lmax, h->glen[g]);
+        glen[g] = (int32_t) lengths[g];
+        goff[g + 1] = goff[g] + (int64_t) p * lengths[g];
+        lmax = std::max(lmax, glen[g]);
     }
+    // Down-sampled regime announced by the caller: when no gene can keep more than 12 active columns the run-time-p
+    // kernels serve it row-wise, one wavefront per gene (dn_generic.hip, nmf_rows) -- faster than the column-parallel
+    // templated kernels from p ~ 8 on (p = 16: 76 000 vs 41 000 genes/s per run, p = 32: 5x).
+    const bool rows_regime = h->ds_hint > 1 && p >= 8 && (lmax + h->ds_hint - 1) / h->ds_hint <= 12;
+    const char *force = getenv("DN_FORCE_GENERIC");
+    if (rows_regime && !(force && force[0] == '2')) ks = dn::kernel_set_rows();      // DN_FORCE_GENERIC=2: keep the 256-thread family
+    else if (rows_regime) ks = dn::kernel_set_generic();
+    // commit: the previous data set (if any) is released first, so that a later failure cannot leave old device
+    // buffers behind new host-side shapes
+    free_device(h);
+    h->ks = ks;
+    h->n = n_genes; h->p = p;
+    h->goff.swap(goff); h->glen.swap(glen);
     h->total = h->goff[n_genes];
     h->lmax = lmax;
-    // Down-sampled regime announced by the caller: when no gene can keep more than 12 active columns the run-time-p
-    // kernels serve it row-wise, one wave per gene (dn_generic.hip, nmf_rows) -- faster than the column-parallel
-    // templated kernels from p ~ 8 on (p = 16: 76 000 vs 41 000 genes/s per run, p = 32: 5x).
-    if (rows_regime && (lmax + h->ds_hint - 1) / h->ds_hint <= 12) h->ks = dn::kernel_set_generic();
     return DN_OK;
 }
 
@@ -386,6 +462,14 @@ int dn_set_downsample_hint(dn_handle h, int32_t rate)
     if (!h) return fail(DN_E_INVALID, "null handle");
     if (rate < 1) return fail(DN_E_INVALID, "downsample rate must be >= 1");
     h->ds_hint = rate;
+    return DN_OK;
+}
+
+int dn_set_solver_step_cap(dn_handle h, int32_t max_steps)
+{
+    if (!h) return fail(DN_E_INVALID, "null handle");
+    if (max_steps < 1) return fail(DN_E_INVALID, "the solver step cap must be >= 1");
+    h->max_steps = max_steps;
     return DN_OK;
 }
 
@@ -444,7 +528,7 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     dn::InitArgs a;
     a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.order = h->d_order; a.counter = h->d_counter;
     a.est_sums = h->d_est_sums; a.cov_sums = h->d_cov_sums; a.status = h->d_status; a.n_genes = (int32_t) h->n;
-    a.p = h->p; a.ws = h->d_ws; a.slot_bytes = h->slot_bytes; a.S = h->S;
+    a.p = h->p; a.ws = h->d_ws; a.slot_bytes = h->slot_bytes; a.S = h->S; a.max_steps = h->max_steps;
     HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * 4, h->stream));
     int per_cu = std::max(1, h->ks->blocks_per_cu(1));
     int grid = (int) std::min<int64_t>(h->n, (int64_t) per_cu * h->n_cus);
@@ -481,6 +565,22 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     for (int i = 0; i < h->p; i++) if (!(scale[i] > 0.0) || !std::isfinite(scale[i])) return fail(DN_E_INVALID, "scale factors must be positive and finite");
     HIP_TRY(hipSetDevice(h->device));
 
+    {
+        // the scratch slots were sized at upload (for the announced take-every rate in the one-wave-per-gene family):
+        // grow them if this iteration's rate leaves more active columns than they hold
+        const int32_t rate = prm->downsample_rate;
+        for (auto &C : h->cls) {
+            if (C.n == 0 || !C.ks) continue;
+            const int32_t longest = C.longest;
+            const int32_t need = rate > 1 ? (longest + rate - 1) / rate : longest;
+            if (need > C.S) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                const int rc = size_class(h, C, need);
+                if (rc != DN_OK) return rc;
+                if (&C == &h->cls[0]) { h->slots = C.slots; h->S = C.S; h->slot_bytes = C.slot_bytes; h->d_ws = C.d_ws; }
+            }
+        }
+    }
     if (prm->want_estimates && !h->d_svec)
         HIP_TRY(hipMalloc(&h->d_svec, sizeof(double) * (size_t) std::max<int64_t>(h->svoff[h->n], 1)));
 
@@ -490,7 +590,7 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     a.ds_start = nullptr;
     a.ws = h->d_ws; a.rho = h->d_rho; a.flags = h->d_flags; a.trace = h->d_trace; a.kfin = h->d_kfin; a.emode = h->d_emode;
     a.svec = h->d_svec; a.svoff = h->d_svoff; a.slot_bytes = h->slot_bytes; a.n_genes = (int32_t) h->n; a.S = h->S;
-    a.p = h->p;
+    a.p = h->p; a.rowmax = h->d_rowmax; a.max_steps = h->max_steps;
     a.T = prm->nmf_iter; a.bins = prm->bins; a.min_hc = prm->min_high_coverage; a.rate = prm->downsample_rate;
     a.skip = prm->skip_baseline_selection ? 1 : 0; a.want_est = prm->want_estimates ? 1 : 0;
     for (int i = 0; i < h->p; i++) { a.scale[i] = scale[i]; a.inv_scale[i] = 1.0 / scale[i]; h->last_scale[i] = scale[i]; }

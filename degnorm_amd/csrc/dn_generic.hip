@@ -10,24 +10,47 @@
 // is the identical rank-1 factor -- and so does nmf_rows below, which serves active matrices of at most 12 columns
 // (all of config 4) from registers, one wave per gene, with the machinery of the templated kernels.  The block-wide
 // path (nmf_gen) is about coverage of the interface, not about speed.
+//
+// The file is compiled twice (build.py): -DDN_GEN_NT=256 is the general family (kernel_set_generic), -DDN_GEN_NT=64 the
+// one-wavefront-per-gene family (kernel_set_rows) that serves data sets in which no gene can keep more than NSM_MAX
+// active columns: there only nmf_rows runs, a single wave does all the work of a gene, and 64-thread workgroups let a
+// CU keep 16 genes in flight instead of 2.
 #include <cstdio>
-#define DN_P 8          // sizes the shared reduction scratch only (Smem<8, 256>)
-#define DN_NT 256
+#ifndef DN_GEN_NT
+#define DN_GEN_NT 256
+#endif
+#define DN_P 8          // sizes the shared reduction scratch only (Smem<8, NT>)
+#define DN_NT DN_GEN_NT
 #include "dn_kernels.hpp"
 
+#if DN_GEN_NT == 256
+#define DN_GEN_NS gen
+#undef DN_GEN_MINW
+#define DN_GEN_MINW 2           // two workgroups per CU
+#elif DN_GEN_NT == 64
+#define DN_GEN_NS gen_rows
+#ifndef DN_GEN_MINW
+#define DN_GEN_MINW 4           // <= 128 registers: four waves per SIMD
+#endif
+#else
+#error "DN_GEN_NT must be 256 or 64"
+#endif
+
 namespace dn {
-namespace gen {
+namespace DN_GEN_NS {
 
 constexpr int GP = P_MAX;       // 64
-constexpr int NT = 256;
+constexpr int NT = DN_GEN_NT;
 constexpr int TI = 8;           // rows per reduction tile
 
 struct GState {
     double scale[GP], inv[GP], sumF[GP], rho[GP], K[GP], us[GP], rho_fb[GP], u[GP], y[GP], csum[GP], rsum[GP];
     double S, theta, sig0;
     int32_t status, steps;
-};
+    int32_t max_steps;          // cap of one eigen-solve in MFMA-solver units (IterArgs::max_steps); the plain power
+};                              // iterations below (one step per pass) get 5x that many
 __shared__ GState g_st;
+__shared__ double g_rows_tot[256];     // nmf_rows: the wave's Gram totals (<= 78) and the solver's zero slot
 
 __device__ __forceinline__ void tile_sum(double (&part)[TI])          // totals left in g_sm.tot[0..TI)
 {
@@ -66,7 +89,9 @@ __device__ __forceinline__ double apply_gram(const double *A, double *sj, int n,
 __device__ __forceinline__ int top_singular(const double *A, double *sj, int n, int S, int p)
 {
     const int tid = threadIdx.x;
-    for (int it = 0; it < 20000; it++) {
+    const int cap = 5 * g_st.max_steps;
+    for (int it = 0; ; it++) {
+        if (it >= cap) return ST_NO_CONVERGENCE;
         const double n2 = apply_gram(A, sj, n, S, p);
         if (tid == 0) g_st.steps++;
         if (!(n2 > 0.0)) return ST_ARPACK;
@@ -168,7 +193,7 @@ __device__ __attribute__((noinline)) void nmf_gen(const float *Fb, double *A, do
 // K E = (A v) v^T, so u_s sigma = a_s . v.  Same outputs as nmf_gen.  The other waves of the workgroup wait.
 // ---------------------------------------------------------------------------------------------------
 constexpr int NSM_MAX = 12;                   // widest active matrix the row-wise routine takes
-constexpr int ROWS_ZSLOT = 255;               // last double of g_sm.xw, kept at 0.0 (padding lanes of the solver read it)
+constexpr int ROWS_ZSLOT = 255;               // last double of g_rows_tot, kept at 0.0 (padding lanes of the solver read it)
 
 // NSM: compiled column capacity (4, 8 or 12: the Gram matrix and the solver's tile shrink with it)
 template <int NSM>
@@ -180,7 +205,7 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
     if (wave_id() == 0) {
         const int lane = lane_id();
         const bool live = lane < p;
-        double *tot = &g_sm.xw[0][0];                                   // 256 doubles of wave-private scratch here
+        double *tot = g_rows_tot;
         const double inv_s = live ? g_st.inv[lane] : 0.0;
         double f[NSM], a[NSM], v[NSM];
 #pragma unroll
@@ -195,6 +220,7 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
         EigState<NSM> est;
         double theta = 0.0;
         int steps = 0, st = ST_OK;
+        bool noconv = false;
 #pragma clang loop unroll(disable)
         for (int t = -1; t < T; t++) {                                  // t = -1: SVD of x itself (nmf.py:88)
             if (t >= 0) {
@@ -222,7 +248,9 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             wave_fence();
             if (lane < NSM) tot[lane * (lane + 1) / 2 + lane] -= est.mu;   // the solver takes G - mu I
             wave_fence();
-            steps += top_eig_mfma<NSM>(tot, ROWS_ZSLOT, v, theta, est, t == T - 1);
+            const int r = top_eig_mfma<NSM>(tot, ROWS_ZSLOT, v, theta, est, t == T - 1, g_st.max_steps);
+            steps += r;
+            if (r > g_st.max_steps) noconv = true;
             wave_fence();
         }
         if (st == ST_OK) {
@@ -260,6 +288,7 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             if (live) { g_st.u[lane] = ts / sig; g_st.csum[lane] = cs; g_st.rsum[lane] = fs; }
             if (lane == 0) { g_st.theta = theta; g_st.S = sig * ssum; }
         }
+        if (st == ST_OK && noconv) st = ST_NO_CONVERGENCE;
         if (lane == 0) { g_st.status = st; g_st.steps += steps; }
     }
     __syncthreads();
@@ -279,7 +308,7 @@ __device__ __forceinline__ int fix_k_lds(int p)
     return ST_OK;
 }
 
-__global__ __launch_bounds__(NT, 2) void k_baseline_gen(IterArgs A)      // two workgroups per CU: in the row-wise regime only wave 0 of each works
+__global__ __launch_bounds__(NT, DN_GEN_MINW) void k_baseline_gen(IterArgs A)
 {
     constexpr int W = NT / 64;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -292,6 +321,7 @@ __global__ __launch_bounds__(NT, 2) void k_baseline_gen(IterArgs A)      // two 
     double *rs = sv + S;
     double *sj = rs + S;
     if (tid < p) { g_st.scale[tid] = A.scale[tid]; g_st.inv[tid] = A.inv_scale[tid]; }
+    if (tid == 0) g_st.max_steps = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
     __syncthreads();
 
     for (;;) {
@@ -311,34 +341,31 @@ __global__ __launch_bounds__(NT, 2) void k_baseline_gen(IterArgs A)      // two 
         if (tid == 0) g_st.steps = 0;
         __syncthreads();
 
-        // get_high_coverage_idx (nmf.py:66-76) on F = x / s, true quotients
+        // get_high_coverage_idx (nmf.py:66-76) on F = x / s, true quotients.  max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i)
+        // (division by a positive scalar is monotone): the threshold needs only the row maxima of the raw counts (k_row_max).
         double gm = 0.0;
-        for (int j = tid; j < L; j += NT)
-            for (int i = 0; i < p; i++) { const double f = (double) x[(size_t) i * L + j] / g_st.scale[i]; gm = f > gm ? f : gm; }
         {
-            for (int o = 32; o >= 1; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
-            if (lane == 0) g_sm.xw[w][0] = gm;
-            __syncthreads();
-            gm = g_sm.xw[0][0];
-            for (int ww = 1; ww < W; ww++) gm = fmax(gm, g_sm.xw[ww][0]);
-            __syncthreads();
+            const float *rmx = A.rowmax + (size_t) g * p;
+            for (int i = 0; i < p; i++) { const double f = (double) rmx[i] / g_st.scale[i]; gm = f > gm ? f : gm; }
         }
         const double thr = 0.1 * gm;
+        // candidate columns: every base, or only the systematic sample ds0 + m * rate when down-sampling (nmf.py:223-227)
         const int rate = A.rate;
         const long long ds0 = (rate > 1 && A.ds_start) ? A.ds_start[g] : -1;
-        const int seg = ((L + W - 1) / W + 63) & ~63;
-        const int jb = w * seg, je = (jb + seg < L) ? jb + seg : L;
+        const int M = ds0 >= 0 ? (ds0 < L ? (int) ((L - 1 - ds0) / rate) + 1 : 0) : L;
+        const int seg = ((M + W - 1) / W + 63) & ~63;
+        const int jb = w * seg, je = (jb + seg < M) ? jb + seg : M;
         int base = 0;
         for (int pass = 0; pass < 2; pass++) {
             int run = 0;
             for (int cc = jb; cc < je; cc += 64) {
-                const int j = cc + lane;
+                const int m = cc + lane;
+                const long long j = ds0 >= 0 ? ds0 + (long long) m * rate : (long long) m;
                 bool hi = false;
-                if (j < je) {
+                if (m < je) {
                     double cm = 0.0;
                     for (int i = 0; i < p; i++) { const double f = (double) x[(size_t) i * L + j] / g_st.scale[i]; cm = f > cm ? f : cm; }
                     hi = cm > thr;
-                    if (ds0 >= 0) hi = hi && (j >= ds0) && ((j - ds0) % rate == 0);
                 }
                 const unsigned long long mask = __ballot(hi);
                 if (pass == 1 && hi) {
@@ -527,6 +554,7 @@ __global__ __launch_bounds__(NT, 2) void k_baseline_gen(IterArgs A)      // two 
     }
 }
 
+#if DN_GEN_NT == 256
 // ratio_svd + row sums (nmf.py:109-121, :524-525) for run-time p; uses the same scratch slots.
 // y = A (A^T u) on the RAW fp32 coverage (row stride L) in ONE pass: every thread forms s = u . a_j for its columns and
 // adds s a_j to per-thread partials of all p rows (registers), which are then block-reduced in tiles of 8.  The
@@ -567,7 +595,9 @@ __device__ __forceinline__ double apply_gram_raw(const float *x, int L, int p)
 __device__ __forceinline__ int top_singular_raw(const float *x, int L, int p)
 {
     const int tid = threadIdx.x;
-    for (int it = 0; it < 20000; it++) {
+    const int cap = 5 * g_st.max_steps;
+    for (int it = 0; ; it++) {
+        if (it >= cap) return ST_NO_CONVERGENCE;
         const double n2 = apply_gram_raw(x, L, p);
         if (tid == 0) g_st.steps++;
         if (!(n2 > 0.0)) return ST_ARPACK;
@@ -588,6 +618,8 @@ __global__ __launch_bounds__(NT) void k_ratio_svd_gen(InitArgs A)
 {
     const int tid = threadIdx.x;
     const int p = A.p;
+    if (tid == 0) g_st.max_steps = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
+    __syncthreads();
     for (;;) {
         if (tid == 0) g_sm.gene = atomicAdd(A.counter, 1);
         __syncthreads();
@@ -648,6 +680,8 @@ __global__ __launch_bounds__(NT) void k_ratio_svd_gen(InitArgs A)
     }
 }
 
+#endif  // DN_GEN_NT == 256
+
 __global__ __launch_bounds__(256) void k_estimates_gen(EstArgs A, const int32_t *__restrict__ tile_gene,
                                                        const int32_t *__restrict__ tile_col0)
 {
@@ -686,11 +720,12 @@ static int launch_baseline(const IterArgs &a, int grid, size_t, hipStream_t s)
     hipLaunchKernelGGL(k_baseline_gen, dim3(grid), dim3(NT), 0, s, a);
     return (int) hipGetLastError();
 }
-static void launch_init(const InitArgs &a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_ratio_svd_gen, dim3(grid), dim3(NT), 0, s, a); }
 static void launch_est(const EstArgs &a, const int32_t *tg, const int32_t *tc, int n_tiles, hipStream_t s)
 {
     hipLaunchKernelGGL(k_estimates_gen, dim3(n_tiles), dim3(256), 0, s, a, tg, tc);
 }
+#if DN_GEN_NT == 256
+static void launch_init(const InitArgs &a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_ratio_svd_gen, dim3(grid), dim3(NT), 0, s, a); }
 static int blocks_per_cu(int which)
 {
     int nb = 0;
@@ -698,9 +733,20 @@ static int blocks_per_cu(int which)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd_gen, NT, 0);
     return e == hipSuccess ? nb : 0;
 }
+#else
+// the initial ratio-SVD pass works on whole transcripts: it stays with the 256-thread family
+static void launch_init(const InitArgs &a, int grid, hipStream_t s) { kernel_set_generic()->init(a, grid, s); }
+static int blocks_per_cu(int which)
+{
+    if (which != 0) return kernel_set_generic()->blocks_per_cu(which);
+    int nb = 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline_gen, NT, 0) == hipSuccess ? nb : 0;
+}
+#endif
 
-}  // namespace gen
+}  // namespace gen / gen_rows
 
+#if DN_GEN_NT == 256
 const KernelSet *kernel_set_generic()
 {
     static const KernelSet ks = {
@@ -710,5 +756,16 @@ const KernelSet *kernel_set_generic()
     };
     return &ks;
 }
+#else
+const KernelSet *kernel_set_rows()
+{
+    static const KernelSet ks = {
+        0, gen_rows::NT, gen_rows::launch_baseline, gen_rows::launch_init, gen_rows::launch_est, gen_rows::blocks_per_cu,
+        (size_t) 160 * 1024,
+        "k_baseline_rows",
+    };
+    return &ks;
+}
+#endif
 
 }  // namespace dn

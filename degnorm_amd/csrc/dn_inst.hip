@@ -1,6 +1,7 @@
 // dn_inst.hip -- one translation unit per sample count: hipcc -DDN_P=<p> [-DDN_NT=<threads>] -c dn_inst.hip
 // Instantiates the kernels of dn_kernels.hpp for p = DN_P and exports their launchers as dn_kernel_set_p<DN_P>.
 #include <cstdio>
+#include <mutex>
 #include "dn_kernels.hpp"
 
 #ifndef DN_P
@@ -10,6 +11,7 @@
 #define DN_NT 64
 #endif
 
+#define DN_MAX_DEVICES 64
 #define DN_CAT_(a, b) a##b
 #define DN_CAT(a, b) DN_CAT_(a, b)
 #define DN_STR_(a) #a
@@ -19,12 +21,22 @@ namespace dn {
 
 static int launch_baseline(const IterArgs &a, int grid, size_t dyn_lds, hipStream_t s)
 {
-    static size_t configured = 0;
-    if (dyn_lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_baseline<DN_P, DN_NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn_lds);
-        if (e != hipSuccess) return (int) e;
-        configured = dyn_lds;
+    // The dynamic-LDS opt-in is a property of the function ON A DEVICE (each device loads its own copy of the code
+    // object), so it is tracked per device: a process that opens handles on two GPUs configures both.
+    static std::mutex mu;
+    static size_t configured[DN_MAX_DEVICES] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int) e;
+    if (dev < 0 || dev >= DN_MAX_DEVICES) return (int) hipErrorInvalidDevice;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (dyn_lds > configured[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_baseline<DN_P, DN_NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn_lds);
+            if (e != hipSuccess) return (int) e;
+            configured[dev] = dyn_lds;
+        }
     }
     hipLaunchKernelGGL((k_baseline<DN_P, DN_NT>), dim3(grid), dim3(DN_NT), dyn_lds, s, a);
     return (int) hipGetLastError();

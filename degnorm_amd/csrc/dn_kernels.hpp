@@ -7,16 +7,18 @@
 //   k_ratio_svd<P,NT>  ratio_svd + row sums                                    nmf.py:109-121, :524-525
 //   k_estimates<P>     the `estimate` output of baseline_selection             nmf.py:327-365
 //
-// Mapping: one workgroup of NT threads (NT/64 wavefronts; NT = 64 is "one wavefront per gene") owns one
-// gene at a time and walks the whole baseline-selection state machine for it; workgroups are persistent
-// and pull genes from a longest-first queue.  Columns (base positions) are spread over lanes, the p
-// samples of a column live in one lane's registers, so every global / LDS access is lane-contiguous.
+// Mapping: one workgroup of NT threads (NT / 64 wavefronts) owns one gene at a time and walks the whole
+// baseline-selection state machine for it; workgroups are persistent and pull genes from a work queue.  Columns (base
+// positions) are spread over lanes, the p samples of a column live in one lane's registers, so every global / LDS
+// access is lane-contiguous.
 //
-// The rank-1 SVD: est = K E = u u^T (x + lambda) is column-local once u is known, so one pass per inner
-// NMF-OA iteration updates lambda AND accumulates the p x p Gram matrix of the *next* x + lambda in
-// registers (fp64).  The Gram partials are reduced through LDS (transposed tree, no atomics, fixed
-// order => deterministic), and every lane then runs the same warm-started power iteration on the tiny
-// matrix to machine precision (the reference's ARPACK call is tol=0).  No MFMA: p << 64.
+// The rank-1 SVD: est = K E = u u^T (x + lambda) is column-local once u is known, so one pass per inner NMF-OA
+// iteration updates the state a = x + lambda AND accumulates the p x p Gram matrix of the *next* a in registers (fp64).
+// The per-lane Gram partials are reduce-scattered inside each wave in registers (dn_reduce.hpp: v_permlane swaps + DPP,
+// fixed order => deterministic, no atomics), added across waves through LDS, and the top eigenvector of the p x p
+// matrix comes from repeated squaring on the fp64 matrix cores (top_eig_mfma, p <= 16; v_mfma_f64_16x16x4_f64) or a
+// row-distributed shifted power iteration (p > 16), to fp64 round-off like the reference's ARPACK call with tol = 0.
+// For p >= DN_MG_MIN_P the Gram matrix itself is accumulated on the matrix cores (mg_core).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -57,7 +59,9 @@ enum { EXIT_LOW_COV = 0, EXIT_ZERO_SAMPLE = 1, EXIT_MEDIAN = 2, EXIT_NO_LOOP = 3
        EXIT_REFINED = 4, EXIT_REFINE_FALLBACK = 5, EXIT_NOT_FOUND_FALLBACK = 6 };
 enum { LOOP_NATURAL = 0, LOOP_PERFECT = 1, LOOP_VALUE_ERROR = 2, LOOP_ZERO_ROWSUM = 3, LOOP_MIN_BINS = 4,
        LOOP_NOT_ENTERED = 5 };
-enum { ST_OK = 0, ST_ARPACK = -1, ST_EMPTY_MIN = -2, ST_VALUE_ERROR = -3 };
+enum { ST_OK = 0, ST_ARPACK = -1, ST_EMPTY_MIN = -2, ST_VALUE_ERROR = -3,
+       ST_NO_CONVERGENCE = -4 };     // an eigen-solve left through its step cap (ARPACK would raise ArpackNoConvergence)
+constexpr int EIG_MAX_STEPS_DEFAULT = 4000;
 // how k_estimates rebuilds a gene's estimate
 enum { EM_INPUT = 0,        // defaults: estimate = F                                   nmf.py:217
        EM_EXPAND = 1,       // n0 < L: K fixed-up, E = max_i F/K, est = max(K E, F)      nmf.py:358-365
@@ -72,6 +76,7 @@ struct IterArgs {
     const int32_t *order;      // work queue: gene ids, longest first
     int32_t       *counter;    // queue head
     const int64_t *ds_start;   // per gene, or nullptr
+    const float   *rowmax;     // n x p: max_j x[i][j] of the raw coverage (k_row_max, once per upload)
     char          *ws;         // scratch: slots x slot_bytes
     double        *rho;        // n x p
     int32_t       *flags;      // n
@@ -86,6 +91,7 @@ struct IterArgs {
     int32_t        lds_cols;   // lambda columns held in LDS (dynamic shared memory = 8 * p * lds_cols bytes)
     int32_t        T, bins, min_hc, rate, skip, want_est;
     int32_t        p;          // samples (run-time copy; the templated kernels take it from the template)
+    int32_t        max_steps;  // step cap of one eigen-solve (power-step equivalents); beyond it the gene gets ST_NO_CONVERGENCE
     double         scale[P_MAX];
     double         inv_scale[P_MAX];
 };
@@ -101,6 +107,7 @@ struct InitArgs {
     int32_t       *status;     // n
     int32_t        n_genes;
     int32_t        p;
+    int32_t        max_steps;
     char          *ws;         // scratch slots (generic kernels only)
     int64_t        slot_bytes;
     int32_t        S;
@@ -290,7 +297,7 @@ __device__ __forceinline__ void sym_matvec(const double (&G)[P * (P + 1) / 2], c
 }
 
 template <int P>
-__device__ __forceinline__ int top_eig(const double (&G)[P * (P + 1) / 2], double (&u)[P], double &theta)
+__device__ __forceinline__ int top_eig(const double (&G)[P * (P + 1) / 2], double (&u)[P], double &theta, int maxs = EIG_MAX_STEPS_DEFAULT)
 {
     double tr = 0.0;
 #pragma unroll
@@ -323,7 +330,8 @@ __device__ __forceinline__ int top_eig(const double (&G)[P * (P + 1) / 2], doubl
 #pragma unroll
         for (int i = 0; i < P; i++) th = fma(u[i], y[i], th);
         steps++;
-        if (d2 <= 1e-24 || steps >= 4000) break;
+        if (d2 <= 1e-24) break;
+        if (steps >= maxs) { steps = maxs + 1; break; }          // > maxs tells the caller the cap was hit
     }
     theta = th;
     return steps;
@@ -393,7 +401,7 @@ __device__ __forceinline__ void eig_state_cold(EigState<P> &st, double tr)
 // theta the eigenvalue of G: exact (Rayleigh quotient) when asked for, else an estimate that only feeds the next shift.
 template <int P>
 __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double (&u)[P], double &theta, EigState<P> &st,
-                                            bool exact_theta)
+                                            bool exact_theta, int maxs = EIG_MAX_STEPS_DEFAULT)
 {
     static_assert(P <= 16, "one 16 x 16 MFMA tile");
     constexpr int KB = EigState<P>::KB;
@@ -450,7 +458,8 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
     int steps = 1 + (2 << M);
     // as in top_eig_rows: stop when the error predicted from the contraction between two checks is ~1e-13
     // (ratio = d2 / d2_prev < 0.25 and 4 d2 ratio <= 1e-26, written without the division)
-    while (!(d2 <= 1e-26 || (4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev)) && steps < 4000) {
+    bool conv;
+    while (!(conv = (d2 <= 1e-26 || (4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev))) && steps < maxs) {
         const dn_double4 y = mfma_sym<KB>(h, v);
         double part = 0.0;
 #pragma unroll
@@ -495,7 +504,7 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
     st.sc = __builtin_amdgcn_rcp(tr);
     double mn = (tr - theta) * (1.0 / (double) (P > 1 ? P - 1 : 1));
     st.mu = (theta > 0.0 && mn > 0.0 && mn < 0.5 * theta) ? mn : 0.0;
-    return steps + 1;
+    return conv ? (steps < maxs ? steps + 1 : maxs) : maxs + 1;         // > maxs: left through the step cap
 }
 
 // Sample counts above 16 (more than one MFMA tile): shifted power iteration with the matrix distributed by rows --
@@ -522,7 +531,7 @@ __device__ __forceinline__ double row_dot(const double (&Gr)[P], const double (&
 }
 
 template <int P>
-__device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], double &theta)
+__device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], double &theta, int maxs = EIG_MAX_STEPS_DEFAULT)
 {
     static_assert(P <= 64, "one row per lane");
     const int r = lane_id() < P ? lane_id() : P - 1;
@@ -549,6 +558,7 @@ __device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], d
 #pragma unroll
     for (int i = 0; i < P; i++) v[i] = fma(-mu, u[i], w[i]);             // first shifted step
     int steps = 1;
+    bool capped = false;
     double d2_prev = -1.0;
     for (;;) {
         double n2 = 0.0;
@@ -564,7 +574,8 @@ __device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], d
             d2 = fma(d, d, d2);
             u[i] = un;
         }
-        if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev) || steps >= 4000) break;
+        if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev)) break;
+        if (steps >= maxs) { capped = true; break; }
         d2_prev = d2;
         bcast_rows<P>(row_dot<P>(Gr, u), w);                           // two plain steps, no normalisation in between
         bcast_rows<P>(row_dot<P>(Gr, w), v);
@@ -575,7 +586,7 @@ __device__ __forceinline__ int top_eig_rows(const double *tot, double (&u)[P], d
 #pragma unroll
     for (int i = 0; i < P; i++) th = fma(u[i], w[i], th);
     theta = th;
-    return steps + 1;
+    return capped ? maxs + 1 : (steps < maxs ? steps + 1 : maxs);
 }
 
 // The same iteration for wide cohorts: lane l keeps row l of G in registers (p doubles) and ITS component of the
@@ -605,7 +616,7 @@ __device__ __forceinline__ double lds_row_dot(const double (&Gr)[P], const doubl
 }
 
 template <int P>
-__device__ __forceinline__ int top_eig_rows_lds(const double *tot, double *uv, double *vv, double &theta)
+__device__ __forceinline__ int top_eig_rows_lds(const double *tot, double *uv, double *vv, double &theta, int maxs = EIG_MAX_STEPS_DEFAULT)
 {
     static_assert(P <= 64, "one row per lane");
     const int lane = lane_id();
@@ -626,6 +637,7 @@ __device__ __forceinline__ int top_eig_rows_lds(const double *tot, double *uv, d
     mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
     double vl = fma(-mu, ul, y);                                        // first shifted step
     int steps = 1;
+    bool capped = false;
     double d2_prev = -1.0;
     for (;;) {
         const double n2 = wave_allsum(vl * vl);
@@ -638,7 +650,8 @@ __device__ __forceinline__ int top_eig_rows_lds(const double *tot, double *uv, d
         wave_fence();
         if (live) uv[r] = ul;
         wave_fence();
-        if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev) || steps >= 4000) break;
+        if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev)) break;
+        if (steps >= maxs) { capped = true; break; }
         d2_prev = d2;
         const double wl = fma(-mu, ul, lds_row_dot<P>(Gr, uv));        // two plain shifted steps, no normalisation in between
         if (live) vv[r] = wl;
@@ -649,7 +662,7 @@ __device__ __forceinline__ int top_eig_rows_lds(const double *tot, double *uv, d
     }
     y = lds_row_dot<P>(Gr, uv);                                         // Rayleigh quotient of the unshifted matrix
     theta = wave_allsum(ul * y);
-    return steps + 1;
+    return capped ? maxs + 1 : (steps < maxs ? steps + 1 : maxs);
 }
 
 // One interface over the two solvers: the MFMA squaring solver with its carried state for p <= 16, the row-distributed
@@ -660,8 +673,8 @@ template <int P> struct Solver<P, true> {
     __device__ __forceinline__ void cold(double tr, double (&u)[P]) { (void) u; eig_state_cold<P>(st, tr); }
     __device__ __forceinline__ double shift() const { return st.mu; }
     static constexpr bool SHIFTED = true;
-    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact)
-    { return top_eig_mfma<P>(tot, zslot, u, theta, st, exact); }
+    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs)
+    { return top_eig_mfma<P>(tot, zslot, u, theta, st, exact, maxs); }
 };
 template <int P> struct Solver<P, false> {
     __device__ __forceinline__ void cold(double tr, double (&u)[P])
@@ -673,8 +686,8 @@ template <int P> struct Solver<P, false> {
     }
     __device__ __forceinline__ double shift() const { return 0.0; }
     static constexpr bool SHIFTED = false;
-    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact)
-    { (void) zslot; (void) exact; return top_eig_rows<P>(tot, u, theta); }
+    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs)
+    { (void) zslot; (void) exact; return top_eig_rows<P>(tot, u, theta, maxs); }
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
@@ -767,6 +780,7 @@ struct GeneState {
     double sums[2 * P + 1];   // { sum_j s_j, clamped row sums (P), row sums of Fb (P) }
     int32_t steps;       //   power-iteration steps spent (accumulated over the gene's calls)
     int32_t status;
+    int32_t max_steps;   // step cap of one eigen-solve (IterArgs::max_steps)
     long long stamp[4];  // diagnostic builds (DN_STAMP): cycles in pass / reduction / eigen-solver
 };
 
@@ -926,7 +940,7 @@ __device__ __forceinline__ gdouble_ptr spill_ptr(gdouble_ptr Lg, int k)
 // ---------------------------------------------------------------------------------------------------
 template <int P, int NT>
 __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, int n, int nL, int T,
-                                       double (&u)[P], double &theta, int &steps)
+                                       double (&u)[P], double &theta, int &steps, int maxs, bool &noconv)
 {
     constexpr int W = NT / 64;
     constexpr int NG = P * (P + 1) / 2;
@@ -1065,11 +1079,12 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
         const double tr = wave_allsum(lane < P ? sm.tot[lane * (lane + 1) / 2 + lane] : 0.0);
         if (!(tr > 0.0)) return ST_ARPACK;
     }
-    steps += top_eig_rows_lds<P>(sm.tot, uv, vv, theta);
+    { const int r = top_eig_rows_lds<P>(sm.tot, uv, vv, theta, maxs); steps += r; noconv = noconv || r > maxs; }
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
         pass(false, t);
-        steps += top_eig_rows_lds<P>(sm.tot, uv, vv, theta);
+        const int r = top_eig_rows_lds<P>(sm.tot, uv, vv, theta, maxs);
+        steps += r; noconv = noconv || r > maxs;
     }
     bcast_rows<P>(lane < P ? uv[lane] : 0.0, u);                        // the final pass wants u as a uniform array
     return ST_OK;
@@ -1096,6 +1111,8 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     const bool first = __builtin_amdgcn_readfirstlane(first_i) != 0;
     double inv[P], u[P], theta = 0.0;
     int steps = 0;
+    const int maxs = __builtin_amdgcn_readfirstlane(g_gs.max_steps);
+    bool noconv = false;
 #pragma unroll
     for (int i = 0; i < P; i++) inv[i] = uniform(g_gs.inv[i]);
     long long stamp[4] = {0, 0, 0, 0};
@@ -1119,7 +1136,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     const int tid = threadIdx.x;
     const int nLe = (n < nL) ? n : nL;                     // end of the LDS tier
     if constexpr (P >= DN_MG_MIN_P) {
-        const int st = mg_core<P, NT>(Fb, Lg, lam, n, nL, T, u, theta, steps);
+        const int st = mg_core<P, NT>(Fb, Lg, lam, n, nL, T, u, theta, steps, maxs, noconv);
         if (st != ST_OK) { if (tid == 0) g_gs.status = st; __syncthreads(); return; }
     } else {
     gram_t G[CH];
@@ -1161,7 +1178,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         for (int i = 0; i < P; i++) tr += sm.tot[i * (i + 1) / 2 + i];
         solver.cold(tr, u);
     }
-    steps += solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, T == 0);
+    { const int r = solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, T == 0, maxs); steps += r; noconv = noconv || r > maxs; }
 #pragma unroll
     for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
 
@@ -1279,7 +1296,8 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             block_sum_lds<NQ, P, NT, gram_t, Solver<P>::SHIFTED, Q * CH>(Gq, g_sm, solver.shift());
         });
         { DN_T0();
-        steps += solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, t == T - 1);   // sigma^2 is only read after the last solve
+        const int r = solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, t == T - 1, maxs);   // sigma^2 is only read after the last solve
+        steps += r; noconv = noconv || r > maxs;
 #pragma unroll
         for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
         DN_T1(2); }
@@ -1314,7 +1332,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         for (int i = 0; i < P; i++) g_gs.u[i] = u[i];
         g_gs.theta = theta;
         g_gs.steps += steps;
-        g_gs.status = ST_OK;
+        g_gs.status = noconv ? ST_NO_CONVERGENCE : ST_OK;
 #ifdef DN_STAMP
         g_gs.stamp[0] += stamp[0]; g_gs.stamp[1] += stamp[1]; g_gs.stamp[2] += stamp[2];
 #endif
@@ -1352,6 +1370,7 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
     double *sv = Lg + (size_t) P * S;                                 // s_start                        [S]
     double *rs = sv + S;                                              // residual profile               [S]
     if (tid < P) gs.inv[tid] = A.inv_scale[tid];
+    if (tid == 0) gs.max_steps = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
     for (int t = tid; t < Smem<P, NT>::NX; t += NT) {                  // constants of the eigen-solver (top_eig_mfma)
         bool diag = false;
 #pragma unroll
@@ -1381,27 +1400,24 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
         if (tid == 0) { gs.steps = 0; gs.stamp[0] = gs.stamp[1] = gs.stamp[2] = 0; }
 
         // ---- get_high_coverage_idx (nmf.py:66-76) on F = x / s (nmf.py:146) -------------------------
-        // max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): division by a positive scalar is monotone.
+        // max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): division by a positive scalar is monotone, so the global maximum
+        // of the scaled matrix needs only the p row maxima of the RAW counts, computed once per upload (k_row_max).
         double thr;
         {
-            float rmx[P];
-#pragma unroll
-            for (int i = 0; i < P; i++) rmx[i] = 0.0f;
-            for (int j = tid; j < L; j += NT) {
-#pragma unroll
-                for (int i = 0; i < P; i++) rmx[i] = fmaxf(rmx[i], x[(size_t) i * L + j]);
-            }
-            block_max_f<P, P, NT>(rmx, sm);
+            const float *rmx = A.rowmax + (size_t) g * P;
             double gmax = (double) rmx[0] / A.scale[0];
 #pragma unroll
             for (int i = 1; i < P; i++) { const double v = (double) rmx[i] / A.scale[i]; gmax = v > gmax ? v : gmax; }
             thr = 0.1 * gmax;
         }
 
+        // Candidate columns: every base, or -- when down-sampling -- only the systematic sample ds0 + m * rate
+        // (nmf.py:223-227: the high-coverage test is intersected with the sample, so columns outside it are never read).
         const int rate = A.rate;
         const long long ds0 = (rate > 1 && A.ds_start) ? A.ds_start[g] : -1;
-        const int seg = ((L + W - 1) / W + 63) & ~63;
-        const int jb = w * seg, je = (jb + seg < L) ? jb + seg : L;
+        const int M = ds0 >= 0 ? (ds0 < L ? (int) ((L - 1 - ds0) / rate) + 1 : 0) : L;
+        const int seg = ((M + W - 1) / W + 63) & ~63;
+        const int jb = w * seg, je = (jb + seg < M) ? jb + seg : M;
 
         // pass 1: count per wave segment; pass 2: ordered compaction of the raw counts into Fs / Fb (nmf.py:236-238).
         // The threshold test uses the true quotient x / s so that ties resolve exactly as in the reference.
@@ -1413,16 +1429,16 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
             for (int pass = 0; pass < 2; pass++) {
                 int run = 0;
                 for (int c = jb; c < je; c += 64) {
-                    const int j = c + lane;
+                    const int m = c + lane;
                     bool hi = false;
                     float xv[P];
                     double f[P];
-                    if (j < je) {
+                    if (m < je) {
+                        const long long j = ds0 >= 0 ? ds0 + (long long) m * rate : (long long) m;
                         double cm = 0.0;
 #pragma unroll
                         for (int i = 0; i < P; i++) { xv[i] = x[(size_t) i * L + j]; f[i] = (double) xv[i] / A.scale[i]; cm = f[i] > cm ? f[i] : cm; }
                         hi = cm > thr;
-                        if (ds0 >= 0) hi = hi && (j >= ds0) && ((j - ds0) % rate == 0);   // nmf.py:223-227
                     }
                     const unsigned long long mask = __ballot(hi);
                     if (pass == 1 && hi) {
@@ -1688,7 +1704,8 @@ __global__ __launch_bounds__(NT) void k_ratio_svd(InitArgs A)
                 double u[P], theta;
 #pragma unroll
                 for (int i = 0; i < P; i++) u[i] = 1.0 / sqrt((double) P);
-                top_eig<P>(G, u, theta);
+                const int maxs = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
+                if (top_eig<P>(G, u, theta, maxs) > maxs) status = ST_NO_CONVERGENCE;
                 for (int j = tid; j < L; j += NT) {
                     double v[P], s = 0.0;
 #pragma unroll

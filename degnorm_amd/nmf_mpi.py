@@ -87,6 +87,11 @@ class TorchComm(object):
         self.dist.all_gather_object(out, obj, group=self.group)
         return out
 
+    def bcast_object(self, obj, root=0):
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=root, group=self.group)
+        return box[0]
+
     # point-to-point object passing, for callers that drive this like an mpi4py communicator
     def send(self, obj, dest, tag=0):
         self.dist.send_object_list([obj], dst=dest, group=self.group)
@@ -118,6 +123,21 @@ def _allreduce(comm, vec):
     return comm.recv(source=0, tag=888 + comm.rank)
 
 
+def _bcast(comm, obj):
+    """Rank 0's `obj` on every rank."""
+    if comm.size == 1:
+        return obj
+    if hasattr(comm, 'bcast_object'):
+        return comm.bcast_object(obj, root=0)
+    if hasattr(comm, 'bcast'):                # mpi4py
+        return comm.bcast(obj, root=0)
+    if comm.rank == 0:
+        for r in range(1, comm.size):
+            comm.send(obj, dest=r, tag=555 + r)
+        return obj
+    return comm.recv(source=0, tag=555 + comm.rank)
+
+
 def _gather(comm, obj):
     if hasattr(comm, 'gather_objects'):
         return comm.gather_objects(obj)
@@ -133,10 +153,11 @@ def _gather(comm, obj):
 class ShardedNMFOA(object):
     """
     One rank's share of a DegNorm run: a resident gene shard on one GPU plus the replicated per-sample state.
+    A rank may hold NO genes (more ranks than gene chunks, nmf_mpi.py:613): it then contributes zeros to every collective.
     """
 
     def __init__(self, comm=None, device=None, degnorm_iter=5, downsample_rate=1, min_high_coverage=50,
-                 nmf_iter=100, bins=20, skip_baseline_selection=False, random_state=123, dev=None):
+                 nmf_iter=100, bins=20, skip_baseline_selection=False, random_state=123):
         self.comm = comm if comm is not None else LocalComm()
         self.degnorm_iter = abs(int(degnorm_iter))
         self.nmf_iter = abs(int(nmf_iter))
@@ -147,43 +168,65 @@ class ShardedNMFOA(object):
             self.min_high_coverage = 2                    # nmf_mpi.py:594-596
         self.skip_baseline_selection = skip_baseline_selection
         self.random_state = random_state
-        dev_id = int(os.environ.get('LOCAL_RANK', 0)) if device is None else int(device)
-        # `dev` lets a caller supply an already-open Device (or, in the CPU test-suite, a stand-in with the
-        # same interface); the product path always opens the HIP device and raises if there is none.
-        self.dev = dev if dev is not None else _lib.Device(dev_id)
+        self._dev_id = int(os.environ.get('LOCAL_RANK', 0)) if device is None else int(device)
+        self._dev = None           # the HIP device, opened on first use; no fallback: without the library or a GPU it raises
         self.kernel_ms = []
         self.traces = []
         self.class_ms = []
         self.downsample_offsets = None                    # optional (degnorm_iter x n_local) explicit starts
         self.n_local = 0
+        self.n_total = 0
+        self.global_ids = None
+        self.p = 0
+
+    @property
+    def dev(self):
+        if self._dev is None:
+            self._dev = _lib.Device(self._dev_id)
+        return self._dev
 
     # -- data -------------------------------------------------------------------------------------
-    def load(self, cov_mats, reads):
-        if hasattr(self.dev, 'hint_downsample'):
+    def load(self, cov_mats, reads, global_ids=None, n_total=None, p=None):
+        """cov_mats: this rank's (p x L_g) matrices; global_ids: their positions in the whole data set (for the
+        partition-invariant down-sampling offsets); n_total: genes over all ranks."""
+        if len(cov_mats) > 0:
             self.dev.hint_downsample(self.downsample_rate)
-        self.dev.upload(cov_mats)
-        self._set_reads(reads)
+            self.dev.upload(cov_mats)
+            if getattr(self.dev, 'inexact', 0):
+                logging.warning('{0} coverage values are not exactly representable in float32; they were rounded '
+                                'on upload.'.format(self.dev.inexact))
+            p = self.dev.p
+        self._set_reads(reads, len(cov_mats), p, global_ids, n_total)
 
-    def load_packed(self, packed, lengths, p, reads):
-        if hasattr(self.dev, 'hint_downsample'):
+    def load_packed(self, packed, lengths, p, reads, global_ids=None, n_total=None):
+        if len(lengths) > 0:
             self.dev.hint_downsample(self.downsample_rate)
-        self.dev.upload_packed(packed, lengths, p)
-        self._set_reads(reads)
+            self.dev.upload_packed(packed, lengths, p)
+        self._set_reads(reads, len(lengths), p, global_ids, n_total)
 
-    def _set_reads(self, reads):
-        self.x = np.array(reads, dtype=np.float64).reshape(self.dev.n, self.dev.p)
-        self.n_local, self.p = self.dev.n, self.dev.p
+    def _set_reads(self, reads, n_local, p, global_ids, n_total):
+        if p is None:
+            raise ValueError('an empty shard needs the sample count p')
+        self.n_local, self.p = int(n_local), int(p)
+        self.x = np.array(reads, dtype=np.float64).reshape(self.n_local, self.p)
+        self.global_ids = np.arange(self.n_local) if global_ids is None else np.asarray(global_ids, dtype=np.int64)
+        if self.global_ids.shape != (self.n_local,):
+            raise ValueError('global_ids must name every local gene')
+        self.n_total = int(n_total) if n_total is not None else self.n_local
 
     # -- algorithm --------------------------------------------------------------------------------
     def initialize(self):
         """ratio-SVD DI scores and the initial normalisation factors (nmf.py:521-535, nmf_mpi.py:681-718)."""
-        est_sums, cov_sums, status = self.dev.ratio_svd_sums()
+        p = self.p
+        if self.n_local > 0:
+            est_sums, cov_sums, status = self.dev.ratio_svd_sums()
+        else:
+            est_sums, cov_sums, status = np.zeros((0, p)), np.zeros((0, p)), np.zeros(0, dtype=np.int32)
         n_bad = _allreduce(self.comm, [float(np.sum(status != 0))])[0]
-        if n_bad > 0:
+        if n_bad > 0:                                                 # every rank raises together
             raise ValueError('rank-1 SVD failed on {0} gene(s) during initialisation (all-zero coverage?)'.format(int(n_bad)))
         self.rho = 1 - (cov_sums / (est_sums + 1))
-        low = self.rho.max(axis=1) < 0.1
-        p = self.p
+        low = self.rho.max(axis=1) < 0.1 if self.n_local > 0 else np.zeros(0, dtype=bool)
         part = np.concatenate([self.x[low].sum(axis=0), self.x.sum(axis=0), [float(low.sum())]])
         tot = _allreduce(self.comm, part)
         count_sums = tot[:p] if tot[2 * p] > 0 else tot[p:2 * p]
@@ -194,35 +237,57 @@ class ShardedNMFOA(object):
         self._rng = np.random.RandomState(self.random_state)
         self.x_adj = None
         self.kernel_ms, self.traces, self.class_ms = [], [], []
+        self.n_failed = []
         return self.scale_factors
+
+    def _offsets(self, i):
+        """
+        Systematic-sample starts of this rank's genes for outer iteration i (nmf.py:422).  One stream for the WHOLE data
+        set, indexed by global gene id: every rank draws the same n_total numbers and keeps its own, so a sharded run
+        is partition-invariant and equals GeneNMFOA.run with the same random_state.
+        """
+        if self.downsample_rate <= 1:
+            return None
+        if self.downsample_offsets is not None:
+            return np.asarray(self.downsample_offsets[i], dtype=np.int64)
+        return self._rng.randint(0, self.downsample_rate, size=self.n_total).astype(np.int64)[self.global_ids]
 
     def iterate(self, i, want_estimates=False):
         """One outer DegNorm iteration on this rank's genes + the per-sample all-reduce."""
-        ds = None
-        if self.downsample_rate > 1:
-            ds = (np.asarray(self.downsample_offsets[i], dtype=np.int64) if self.downsample_offsets is not None
-                  else self._rng.randint(0, self.downsample_rate, size=self.n_local).astype(np.int64))
-        rho, flags, trace = self.dev.baseline_iteration(
-            self.scale_factors, nmf_iter=self.nmf_iter, bins=self.bins, min_high_coverage=self.min_high_coverage,
-            downsample_rate=self.downsample_rate, skip_baseline_selection=self.skip_baseline_selection,
-            want_estimates=want_estimates, ds_start=ds)
-        self.kernel_ms.append(self.dev.last_kernel_ms())
+        p = self.p
+        ds = self._offsets(i)
+        if self.n_local > 0:
+            rho, flags, trace = self.dev.baseline_iteration(
+                self.scale_factors, nmf_iter=self.nmf_iter, bins=self.bins, min_high_coverage=self.min_high_coverage,
+                downsample_rate=self.downsample_rate, skip_baseline_selection=self.skip_baseline_selection,
+                want_estimates=want_estimates, ds_start=ds)
+            self.kernel_ms.append(self.dev.last_kernel_ms())
+            if hasattr(self.dev, 'class_kernel_ms'):
+                self.class_ms.append((self.dev.class_kernel_ms(0), self.dev.class_kernel_ms(1)))
+        else:
+            rho, flags, trace = np.zeros((0, p)), np.zeros(0, dtype=bool), np.zeros((0, _lib.TRACE_LEN), dtype=np.int32)
+            self.kernel_ms.append(0.0)
+            self.class_ms.append((0.0, 0.0))
         self.traces.append(trace)
-        if hasattr(self.dev, 'class_kernel_ms'):
-            self.class_ms.append((self.dev.class_kernel_ms(0), self.dev.class_kernel_ms(1)))
         rho[rho > 0.9] = 0.9                                          # nmf.py:398-399
         rho[rho < 0.] = 0.
         self.ran_baseline_selection[:, i] = flags
 
-        p = self.p
         xw = self.x_weighted
-        untouched = rho.max(axis=1) == 0                              # nmf.py:155
+        untouched = rho.max(axis=1) == 0 if self.n_local > 0 else np.zeros(0, dtype=bool)   # nmf.py:155
         touched = ~untouched
         A = (xw[touched] / (1 - rho[touched])).sum(axis=0)
         B = xw[untouched].sum(axis=0)
         Wl = xw.sum(axis=0)
-        tot = _allreduce(self.comm, np.concatenate([A, B, Wl, [float(untouched.sum())]]))
+        n_fail = float(np.sum(trace[:, 6] != 0)) if trace is not None else 0.0
+        n_noconv = float(np.sum(trace[:, 6] == -4)) if trace is not None else 0.0
+        tot = _allreduce(self.comm, np.concatenate([A, B, Wl, [float(untouched.sum()), n_fail, n_noconv]]))
         A, B, Wt, n_untouched = tot[:p], tot[p:2 * p], tot[2 * p:3 * p], tot[3 * p]
+        self.n_failed.append((int(tot[3 * p + 1]), int(tot[3 * p + 2])))
+        if tot[3 * p + 1] > 0:                                        # the same warning on every rank
+            logging.warning('DegNorm iteration {0} -- {1} gene(s) hit a degenerate factorization (the reference would '
+                            'raise), {2} of them an eigen-solve that did not converge; their DI scores were left at 0.'
+                            .format(i + 1, int(tot[3 * p + 1]), int(tot[3 * p + 2])))
         S_pre = A + B                                                 # colsum of the first x_adj  (nmf.py:575)
         if n_untouched > 0:
             avg_di = 1 - (Wt / S_pre)                                 # nmf.py:157
@@ -237,83 +302,124 @@ class ShardedNMFOA(object):
         self.scale_factors = self.scale_factors * self.norm_factors   # nmf.py:590
         return self.scale_factors
 
-    def run(self, want_estimates=True):
+    def run(self, want_estimates=True, flat=False):
+        """Returns the estimates of the last iteration: a list of (p x L) arrays, or (flat buffer, lengths) if `flat`."""
         self.initialize()
         est = None
         for i in range(self.degnorm_iter):
             last = i == self.degnorm_iter - 1
             self.iterate(i, want_estimates=want_estimates and last)
             if want_estimates and last:
-                est = self.dev.fetch_estimates()
+                if self.n_local == 0:
+                    est = (np.zeros(0), np.zeros(0, dtype=np.int64)) if flat else []
+                elif flat:
+                    buf = (self.dev.fetch_estimates_flat() if hasattr(self.dev, 'fetch_estimates_flat')
+                           else np.concatenate([m.ravel() for m in self.dev.fetch_estimates()]))
+                    est = (buf, np.asarray(self.dev.lengths, dtype=np.int64))
+                else:
+                    est = self.dev.fetch_estimates()
         return est
 
 
 # ----------------------------------------------------------------------------------------------- #
+def _pack_f32(mats):
+    """(p x L_g) matrices -> (packed float32, lengths int64, number of values float32 cannot hold exactly)."""
+    lengths = np.array([m.shape[1] for m in mats], dtype=np.int64)
+    if len(mats) == 0:
+        return np.zeros(0, dtype=np.float32), lengths, 0
+    packed = np.concatenate([np.asarray(m, dtype=np.float32).ravel() for m in mats])
+    inexact = int(sum(int(np.count_nonzero(np.asarray(m, dtype=np.float32) != m)) for m in mats if m.dtype != np.float32))
+    return packed, lengths, inexact
+
+
 def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate=1, min_high_coverage=50,
                        nmf_iter=100, bins=20, n_jobs=1, skip_baseline_selection=False, random_state=123,
-                       device=None, dev=None, partition='balanced'):
+                       device=None, partition='balanced'):
     """
     Gene-sharded DegNorm run with the reference's signature (nmf_mpi.py:555-580).  Rank 0 holds
     ``cov_dat`` (OrderedDict gene -> p x L) and ``reads_dat`` (n x p) and ships each worker its share once
-    (nmf_mpi.py:603-629); every rank then keeps its genes on its own GPU.  ``partition`` (extra): 'balanced' deals the
-    genes by length so that every GPU gets the same total length (utils.partition_by_length), 'contiguous' is the
-    reference's equal-count chunking (nmf_mpi.py:605); the results are the same, in the original gene order.
+    (nmf_mpi.py:603-629) -- as ONE packed float32 buffer per worker (the layout the device consumes: half the bytes of
+    the reference's float64 pickles and no per-gene objects); every rank then keeps its genes on its own GPU.
+    ``partition`` (extra): 'balanced' deals the genes by length so that every GPU gets the same total length
+    (utils.partition_by_length), 'contiguous' is the reference's equal-count chunking (nmf_mpi.py:605); per-gene
+    results do not depend on it (the down-sampling offsets are drawn per global gene id), rows come back in the
+    original order.  Input errors found on rank 0 are raised on EVERY rank (nobody is left waiting in a receive), and
+    a rank without genes (fewer chunks than ranks, nmf_mpi.py:613) takes part in the collectives with zeros.
     Returns, on rank 0, {'estimates': {gene: p x L}, 'rho', 'x_adj', 'ran_baseline_selection'} in the
     original gene order (nmf_mpi.py:852-860), None elsewhere.
     """
     size, rank = comm.size, comm.rank
+    err, parts, n_genes, p = None, None, 0, 0
     if rank == 0:
-        all_genes = list(cov_dat.keys())
-        n_genes = len(all_genes)
-        x = np.array(reads_dat, dtype=np.float64)
-        if x.shape[0] != n_genes:
-            raise ValueError('Number of genes in read count matrix not equal to number of coverage matrices!')
-        if not all(z.ndim == 2 for z in cov_dat.values()):
-            raise ValueError('Not all coverage matrices are 2-d arrays!')
-        li_vec = np.array([z.shape[1] for z in cov_dat.values()])
-        if abs(int(downsample_rate)) > 1 and not np.min(li_vec) >= abs(int(downsample_rate)):
-            raise ValueError('downsample_rate is too large; take-every size > at least one gene.')
-        if partition == 'contiguous':
-            parts = split_into_chunks(list(range(n_genes)), size)    # nmf_mpi.py:605
-        elif partition == 'balanced':
-            parts = partition_by_length(li_vec, size)
-        else:
-            raise ValueError("partition must be 'balanced' or 'contiguous'")
-        while len(parts) < size:                                      # fewer chunks than ranks: idle ranks get nothing
-            parts.append([])
-        for r in range(1, size):
+        try:
+            all_genes = list(cov_dat.keys())
+            n_genes = len(all_genes)
+            x = np.array(reads_dat, dtype=np.float64)
+            if n_genes == 0:
+                raise ValueError('no coverage matrices')
+            if x.shape[0] != n_genes:
+                raise ValueError('Number of genes in read count matrix not equal to number of coverage matrices!')
+            if not all(getattr(z, 'ndim', 0) == 2 for z in cov_dat.values()):
+                raise ValueError('Not all coverage matrices are 2-d arrays!')
+            li_vec = np.array([z.shape[1] for z in cov_dat.values()])
+            p = int(next(iter(cov_dat.values())).shape[0])
+            if abs(int(downsample_rate)) > 1 and not np.min(li_vec) >= abs(int(downsample_rate)):
+                raise ValueError('downsample_rate is too large; take-every size > at least one gene.')
+            if partition == 'contiguous':
+                parts = split_into_chunks(list(range(n_genes)), size)    # nmf_mpi.py:605
+            elif partition == 'balanced':
+                parts = partition_by_length(li_vec, size)
+            else:
+                raise ValueError("partition must be 'balanced' or 'contiguous'")
+            while len(parts) < size:                                      # fewer chunks than ranks: idle ranks get nothing
+                parts.append([])
+        except ValueError as e:
+            err = str(e)
+    err, n_genes, p = _bcast(comm, (err, n_genes, p))
+    if err is not None:
+        raise ValueError(err)
+
+    if rank == 0:
+        n_inexact = 0
+        for r in range(size - 1, -1, -1):                                # own share last: one packed copy alive at a time
             idx = parts[r]
-            comm.send((OrderedDict((all_genes[k], cov_dat[all_genes[k]]) for k in idx), x[idx]), dest=r, tag=333 + r)
-        my_cov = OrderedDict((all_genes[k], cov_dat[all_genes[k]]) for k in parts[0])
-        my_x = x[parts[0]]
+            packed, lengths, bad = _pack_f32([cov_dat[all_genes[k]] for k in idx])
+            n_inexact += bad
+            if r > 0:
+                comm.send(([all_genes[k] for k in idx], packed, lengths, x[idx], np.asarray(idx, dtype=np.int64)), dest=r, tag=333 + r)
+        if n_inexact:
+            logging.warning('{0} coverage values are not exactly representable in float32; they were rounded on upload.'.format(n_inexact))
+        my_names, my_x, my_ids = [all_genes[k] for k in parts[0]], x[parts[0]], np.asarray(parts[0], dtype=np.int64)
     else:
-        my_cov, my_x = comm.recv(source=0, tag=333 + rank)
+        my_names, packed, lengths, my_x, my_ids = comm.recv(source=0, tag=333 + rank)
 
     eng = ShardedNMFOA(comm=comm, device=device, degnorm_iter=degnorm_iter, downsample_rate=downsample_rate,
                        min_high_coverage=min_high_coverage, nmf_iter=nmf_iter, bins=bins,
-                       skip_baseline_selection=skip_baseline_selection, random_state=random_state, dev=dev)
-    if len(my_cov) == 0:
-        raise ValueError('rank {0} received no genes: more ranks than gene chunks (nmf_mpi.py:613)'.format(rank))
-    eng.load(list(my_cov.values()), my_x)
-    est = eng.run(want_estimates=True)
+                       skip_baseline_selection=skip_baseline_selection, random_state=random_state)
+    eng.load_packed(packed, lengths, p, my_x, global_ids=my_ids, n_total=n_genes)
+    del packed
+    flat, lens = eng.run(want_estimates=True, flat=True)
     logging.info('({0}/{1}) -- finished {2} genes'.format(rank + 1, size, eng.n_local))
 
-    pieces = _gather(comm, (list(my_cov.keys()), est, eng.rho, eng.x_adj, eng.ran_baseline_selection))
+    pieces = _gather(comm, (my_names, flat, lens, eng.rho, eng.x_adj, eng.ran_baseline_selection))
     comm.Barrier()
     if rank != 0:
         return None
     by_name = dict()
-    for genes_r, est_r, _, _, _ in pieces:
-        by_name.update(zip(genes_r, est_r))
+    for genes_r, flat_r, lens_r, _, _, _ in pieces:
+        o = 0
+        for g, L in zip(genes_r, lens_r):
+            by_name[g] = flat_r[o:o + p * int(L)].reshape(p, int(L))
+            o += p * int(L)
     estimates = OrderedDict((g, by_name[g]) for g in all_genes)       # original gene order (nmf_mpi.py:852-860)
 
-    def rows(k):
-        first = pieces[0][k]
-        out = np.empty((n_genes,) + first.shape[1:], dtype=first.dtype)
+    def rows(k, dtype, width):
+        out = np.empty((n_genes, width), dtype=dtype)
         for r, pc in enumerate(pieces):
             out[parts[r]] = pc[k]
         return out
-    return {'estimates': estimates, 'rho': rows(2), 'x_adj': rows(3), 'ran_baseline_selection': rows(4)}
+    return {'estimates': estimates, 'rho': rows(3, np.float64, p), 'x_adj': rows(4, np.float64, p),
+            'ran_baseline_selection': rows(5, bool, abs(int(degnorm_iter)))}
 
 
 def save_results(genes_df, estimates, rho, x_adj, ran_baseline_selection, sample_ids=None, output_dir='.'):

@@ -35,7 +35,9 @@ extern "C" {
 
 #define DN_TRACE_LEN          48  /* int32 per gene; layout mirrors oracle/nmfoa_oracle.c                    */
 /* trace[0] n_hi_cov  [1] #nmf() calls  [2] sum of active columns over calls  [3] exit code
- * [4] loop-exit reason  [5] #dropped bins  [6] status (0 ok; -1 ArpackError, -2 empty min, -3 ValueError)
+ * [4] loop-exit reason  [5] #dropped bins  [6] status (0 ok; -1 ArpackError, -2 empty min, -3 ValueError,
+ *     -4 an eigen-solve left through its step cap: ARPACK's ArpackNoConvergence; the gene's DI row is zeroed like
+ *     the other failures, never filled from an unconverged vector)
  * [7] total power-iteration steps of the on-chip eigen-solver  [8..40) drop_idx sequence                    */
 
 typedef struct dn_handle_s *dn_handle;
@@ -75,6 +77,9 @@ int  dn_destroy(dn_handle h);
  * downsample_rate, nmf.py:36).  Only steers which kernel family serves the data (results do not depend on it): when no
  * gene can keep more than 12 active columns, the row-wise one-wave-per-gene kernels are chosen from p = 8 on.          */
 int  dn_set_downsample_hint(dn_handle h, int32_t rate);
+/* Step cap of one on-chip eigen-solve in power-step equivalents (default 4000; the reference's ARPACK call has
+ * maxiter = 10 n, scipy eigsh via svds, nmf.py:63).  A gene whose solve hits the cap gets status -4.                    */
+int  dn_set_solver_step_cap(dn_handle h, int32_t max_steps);
 int  dn_upload_ragged(dn_handle h, int64_t n_genes, int32_t p, const void *const *genes,
                       const int64_t *lengths, int32_t is_f32, int32_t n_threads, int64_t *inexact);
 int  dn_upload_packed(dn_handle h, int64_t n_genes, int32_t p, const float *packed,

@@ -2,6 +2,9 @@
 Test-only stand-in for degnorm_amd._lib.Device backed by the CPU oracle, so that the host logic above the
 C ABI (sharding, all-reduce algebra, gather, result writing) can be exercised on machines without a GPU.
 It is the CHECKER wearing the device's interface; nothing in the product imports it.
+
+    from _oracle_device import use_oracle_device
+    use_oracle_device()          # degnorm_amd._lib.Device now builds OracleDevice objects (this process only)
 """
 import numpy as np
 
@@ -16,6 +19,9 @@ class OracleDevice(object):
         self.inexact = 0
         self._covs = None
         self._est = None
+
+    def hint_downsample(self, rate):
+        return self
 
     def upload(self, cov_mats, n_threads=0):
         self._covs = [np.ascontiguousarray(c, dtype=np.float64) for c in cov_mats]
@@ -50,3 +56,9 @@ class OracleDevice(object):
 
     def close(self):
         pass
+
+
+def use_oracle_device():
+    """Point the product's device constructor at the stand-in (test processes only; the product has no such switch)."""
+    import degnorm_amd._lib as L
+    L.Device = OracleDevice

@@ -14,6 +14,7 @@ Sections:
     genes      G3     per-gene baseline_selection() outputs + call traces over all gene classes
     run_c1     G4     GeneNMFOA.run on config 1 (100 x 4 x 1000, 1 iteration)
     run_c2     G4     GeneNMFOA.run on a 64-gene draw of config 2 (p=10, L~U[200,5000]), 3 iterations
+    run_c2_deep G4    the same on 256 other genes for BASELINE's 5 iterations (both device gene classes, every exit)
     mpi        G5     run_gene_nmfoa_mpi through an in-process fake communicator (2 and 3 ranks)
     dsamp      G6     downsampled runs (rate 50) with captured systematic-sample offsets
     warm       G7     warm-start directory -> filter -> run -> save_results CSVs
@@ -208,6 +209,14 @@ def sec_run_c2():
                   degnorm_iter=3, nmf_iter=100)
 
 
+def sec_run_c2_deep():
+    # the headline configuration at depth: 256 genes (ids disjoint from run_c2), BASELINE's 5 outer iterations, T = 100;
+    # both gene classes of the device (L <= / > ~2047) and every exit of baseline_selection occur (~25 min of reference time)
+    c = synth.CONFIGS['c2']
+    _run_and_save('run_c2_deep', c['seed'], c['n_genes'], c['p'], c['l_min'], c['l_max'], list(range(64, 320)),
+                  degnorm_iter=5, nmf_iter=100, keep_est=2)
+
+
 def sec_dsamp():
     # rate 50 on p=6 genes (L >= 200 > rate); offsets captured in call order (iteration-major, gene-minor).
     _run_and_save('run_dsamp50', 6, 48, 6, 200, 3000, list(range(48)), degnorm_iter=2, nmf_iter=50,
@@ -347,7 +356,7 @@ def sec_merge():
     print('merge done:', len(genes), 'genes', sum(out[g].size for g in genes), 'values')
 
 
-SECTIONS = OrderedDict(kat=sec_kat, genes=sec_genes, run_c1=sec_run_c1, run_c2=sec_run_c2, mpi=sec_mpi,
+SECTIONS = OrderedDict(kat=sec_kat, genes=sec_genes, run_c1=sec_run_c1, run_c2=sec_run_c2, run_c2_deep=sec_run_c2_deep, mpi=sec_mpi,
                        dsamp=sec_dsamp, warm=sec_warm, merge=sec_merge)
 
 if __name__ == '__main__':

@@ -35,13 +35,14 @@ def _gloo_worker(rank, world, port, out_q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi, TorchComm
-    from _oracle_device import OracleDevice
+    from _oracle_device import use_oracle_device
+    use_oracle_device()
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         G, cov_dat = _inputs()
         comm = TorchComm()
         res = run_gene_nmfoa_mpi(comm, cov_dat if rank == 0 else None, G['reads'] if rank == 0 else None,
-                                 degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), dev=OracleDevice())
+                                 degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']))
         if rank == 0:
             out_q.put({k: (v if k != 'estimates' else {g: e.sum(axis=1) for g, e in v.items()}) for k, v in res.items()})
         else:
@@ -66,6 +67,13 @@ def test_world_size_2_gloo_matches_reference_mpi_golden(oracle):
     np.testing.assert_array_equal(res['ran_baseline_selection'], G['mpi2_flags'])
     assert list(res['estimates'].keys()) == list(cov_dat.keys())          # original gene order (nmf_mpi.py:855)
     np.testing.assert_allclose(np.vstack(list(res['estimates'].values())), G['mpi2_est_rowsum'], rtol=1e-9)
+
+
+@pytest.fixture
+def oracle_device(monkeypatch, oracle):
+    """The product's device constructor builds the oracle-backed stand-in for the duration of one test."""
+    from _oracle_device import OracleDevice
+    monkeypatch.setattr('degnorm_amd._lib.Device', OracleDevice)
 
 
 class _ThreadComm(object):
@@ -99,17 +107,16 @@ class _ThreadComm(object):
 
 
 @pytest.mark.parametrize('partition', ['balanced', 'contiguous'])
-def test_three_ranks_send_recv_communicator(oracle, partition):
+def test_three_ranks_send_recv_communicator(oracle_device, partition):
     """Both gene partitions (length-balanced, and the reference's contiguous chunks) give the reference's MPI result."""
     from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi
-    from _oracle_device import OracleDevice
     G, cov_dat = _inputs()
     comm = _ThreadComm(3)
     out = [None] * 3
 
     def work(r):
         out[r] = run_gene_nmfoa_mpi(comm.view(r), cov_dat if r == 0 else None, G['reads'] if r == 0 else None,
-                                    degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), dev=OracleDevice(),
+                                    degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']),
                                     partition=partition)
     ths = [threading.Thread(target=work, args=(r,)) for r in range(3)]
     [t.start() for t in ths]
@@ -134,14 +141,74 @@ def test_partition_by_length_is_balanced_and_complete():
     assert [len(q) for q in partition_by_length([5, 9], 4)] == [1, 1, 0, 0]
 
 
-def test_single_rank_sharded_equals_single_node(oracle):
+def test_single_rank_sharded_equals_single_node(oracle_device):
     """LocalComm (size 1) through the sharded driver == the reference's single-node result."""
     from degnorm_amd.nmf_mpi import ShardedNMFOA
-    from _oracle_device import OracleDevice
     G, cov_dat = _inputs()
-    eng = ShardedNMFOA(degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), dev=OracleDevice())
+    eng = ShardedNMFOA(degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']))
     eng.load(list(cov_dat.values()), G['reads'])
     eng.run(want_estimates=False)
     np.testing.assert_allclose(eng.rho, G['single_rho'], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(eng.x_adj, G['single_x_adj'], rtol=1e-9)
     np.testing.assert_array_equal(eng.ran_baseline_selection, G['single_flags'])
+
+
+def _run_threads(size, cov_dat, reads, **kw):
+    from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi
+    comm = _ThreadComm(size)
+    out, errs = [None] * size, [None] * size
+
+    def work(r):
+        try:
+            out[r] = run_gene_nmfoa_mpi(comm.view(r), cov_dat if r == 0 else None, reads if r == 0 else None, **kw)
+        except Exception as e:          # noqa: BLE001 -- the test inspects what every rank raised
+            errs[r] = e
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(size)]
+    [t.start() for t in ths]
+    [t.join(timeout=600) for t in ths]
+    assert not any(t.is_alive() for t in ths), 'a rank is stuck in a receive or a collective'
+    return out, errs
+
+
+def test_more_ranks_than_gene_chunks(oracle_device):
+    """
+    split_into_chunks may return fewer chunks than ranks (utils.py:176-192: 5 genes on 4 ranks -> chunks of 2, 2, 1; the
+    reference then fails at nmf_mpi.py:613).  Here the idle rank joins every collective with zeros and the result
+    is the single-node one.
+    """
+    G, cov_dat = _inputs()
+    names = list(cov_dat.keys())[:5]
+    sub = OrderedDict((g, cov_dat[g]) for g in names)
+    out1, errs1 = _run_threads(1, sub, G['reads'][:5], degnorm_iter=2, nmf_iter=20, partition='contiguous')
+    out4, errs4 = _run_threads(4, sub, G['reads'][:5], degnorm_iter=2, nmf_iter=20, partition='contiguous')
+    assert errs1 == [None] and errs4 == [None] * 4
+    np.testing.assert_allclose(out4[0]['rho'], out1[0]['rho'], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(out4[0]['x_adj'], out1[0]['x_adj'], rtol=1e-12)
+    assert list(out4[0]['estimates'].keys()) == names
+    for g in names:
+        np.testing.assert_allclose(out4[0]['estimates'][g], out1[0]['estimates'][g], rtol=1e-12)
+
+
+def test_input_errors_are_raised_on_every_rank(oracle_device):
+    """Rank 0's input checks (nmf_mpi.py:645-658) must not leave the workers waiting in comm.recv."""
+    G, cov_dat = _inputs()
+    out, errs = _run_threads(3, cov_dat, G['reads'], degnorm_iter=1, nmf_iter=10, downsample_rate=100000)
+    assert all(isinstance(e, ValueError) and 'downsample_rate is too large' in str(e) for e in errs)
+    out, errs = _run_threads(3, cov_dat, G['reads'][:-1], degnorm_iter=1, nmf_iter=10)
+    assert all(isinstance(e, ValueError) and 'Number of genes in read count matrix' in str(e) for e in errs)
+
+
+def test_downsampled_run_is_partition_invariant(oracle_device):
+    """
+    Down-sampling offsets are drawn per GLOBAL gene id from one stream (nmf.py:422, :556): 1 rank, 3 ranks balanced and
+    3 ranks contiguous give the same DI scores for the same random_state.
+    """
+    G, cov_dat = _inputs()
+    kw = dict(degnorm_iter=2, nmf_iter=20, downsample_rate=20, random_state=7)
+    ref, e0 = _run_threads(1, cov_dat, G['reads'], **kw)
+    bal, e1 = _run_threads(3, cov_dat, G['reads'], partition='balanced', **kw)
+    con, e2 = _run_threads(3, cov_dat, G['reads'], partition='contiguous', **kw)
+    assert e0 == [None] and e1 == [None] * 3 and e2 == [None] * 3
+    for res in (bal, con):
+        np.testing.assert_allclose(res[0]['rho'], ref[0]['rho'], rtol=1e-12, atol=1e-14)
+        np.testing.assert_array_equal(res[0]['ran_baseline_selection'], ref[0]['ran_baseline_selection'])
