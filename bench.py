@@ -1,21 +1,32 @@
 """
-bench.py -- DegNorm NMF-OA hot path on MI355X: genes/sec on BASELINE.json's config 2
-(20 000 synthetic genes x 10 samples, L ~ U[200, 5000], 5 DegNorm iterations, nmf_iter = 100).
+bench.py -- DegNorm NMF-OA hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--genes G]
+    python bench.py [--config c2|c4] [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete DegNorm run over the resident genes: the ratio-SVD initialisation pass plus
-`--iters` (5) outer iterations, each = one launch of the baseline-selection kernel over every gene of the
-rank's shard, the D2H of the DI rows / flags / traces and the per-sample all-reduce (RCCL over xGMI for
-N > 1).  Coverage is generated and uploaded to HBM before the timed region (estimates are not fetched).
-The 20 000 genes are sharded across the N ranks (contiguous chunks like nmf_mpi.py:605), so scaling is
-strong; `value` = total genes / max-over-ranks wall time.
+--config c2 (default; BASELINE.json's metric, configs[1] / configs[2] when sharded): 20 000 synthetic genes x 10
+samples, L ~ U[200, 5000], 5 DegNorm iterations, nmf_iter = 100.
+--config c4 (configs[3]): 50 000 genes x 50 samples, L ~ U[501, 5000], take-every 500, 5 iterations.
 
-Rank 0 prints ONE JSON line with the driver contract fields plus `roofline` and `cpu_baseline`.
+One "step" = one complete DegNorm run over the resident genes: the ratio-SVD initialisation pass plus `--iters` (5)
+outer iterations, each = the baseline-selection kernels over every gene of the rank's shard, the D2H of the DI rows /
+flags / traces and the per-sample all-reduce (RCCL over xGMI under torchrun, also at N = 1).  Coverage is generated and
+uploaded to HBM before the timed region (estimates are not fetched).  The genes are sharded across the N ranks by
+length (utils.partition_by_length), so scaling is strong; `value` = total genes / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line with the driver contract fields plus
+  roofline      the dominant kernel against the resource that binds it (c2: fp64 vector issue, with the measured
+                one-wave issue ceiling as a second peak and SURVEY 8(d)'s algorithmic bytes/s as a named secondary
+                figure; c4: HBM bytes of the initial pass), `traffic` from the committed rocprofv3 PMC passes of THIS
+                source tree (refused when the sources differ from the profiled ones),
+  parity        after the clock stops: the oracle re-runs a sample of genes with the scale factors each timed outer
+                iteration actually used, and the device's DI rows / branch traces of the LAST timed step are compared,
+  cpu_baseline  the oracle on this box's host cores on a bounded sample.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -26,8 +37,31 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # AMD MI355X spec, fp64 vector (= 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz); not in the guide
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz (AMD MI355X spec)
+# tools/ubench/clock_issue.hip on the box (profiles/round2/ubench_clock_issue.txt): one wave alone on a SIMD issues one
+# fp64 FMA per 5.75 cycles (VGPR sources; 6.75 with an SGPR-pair source) at an in-kernel clock of 2.39 GHz, against the
+# 4 cycles of the peak above; four waves per SIMD reach 4.4.  The kernel runs one wave per SIMD (LDS holds one gene).
+FP64_ISSUE_CYCLES_1WAVE = 5.75
+ROUND = 'round2'
+
+
+def source_hash():
+    """sha256 over the kernel sources and the build recipe: identifies the binary build() makes from this tree."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'degnorm_amd', 'csrc', '*.h*'))) + [os.path.join(ROOT, 'degnorm_amd', 'build.py')]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
+def file_sha256(path):
+    h = hashlib.sha256()
+    with open(path, 'rb') as f:
+        for blk in iter(lambda: f.read(1 << 22), b''):
+            h.update(blk)
+    return h.hexdigest()
 
 
 def algorithmic_bytes(trace, lengths, p, nmf_iter, mask=None):
@@ -42,29 +76,41 @@ def algorithmic_bytes(trace, lengths, p, nmf_iter, mask=None):
     return float(per_gene[mask].sum() if mask is not None else per_gene.sum())
 
 
-def pmc_traffic(kernel_name, genes_in_kernel):
+def pmc_traffic(config, kernel_name, genes_in_kernel):
     """
-    HBM bytes per k_baseline launch from the PMC counters.  bench.py cannot collect PMCs itself: the figure comes
-    from the committed rocprofv3 passes of THIS command (profiles/round1/pmc_traffic.json: separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 calibration) and is only reported when the
-    profiled kernel (name and gene class) is the one that just ran.
+    Fabric-side bytes per launch of the dominant kernel from the PMC counters.  bench.py cannot collect PMCs itself: the
+    figure comes from committed rocprofv3 passes of THIS command (tools/profile_round.sh -> profiles/<round>/
+    pmc_traffic_<config>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
+    calibration).  It is reported only when the profile was taken from the same kernel sources (source_hash), kernel
+    and gene count as the run that just finished; otherwise `traffic` is null and the reason is given.
+    FETCH_SIZE / WRITE_SIZE are fabric-side counters: Infinity-Cache hits are included (MI355X guide, HBM section).
     """
-    path = os.path.join(ROOT, 'profiles', 'round1', 'pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', ROUND, 'pmc_traffic_{0}.json'.format(config))
+    info = {'profile': os.path.relpath(path, ROOT), 'side': 'fabric (L2 <-> Infinity Fabric; includes Infinity-Cache hits)'}
     try:
         with open(path) as f:
             d = json.load(f)
-        if d.get('kernel') == kernel_name and int(d.get('genes_in_kernel', -1)) == int(genes_in_kernel):
-            return float(d['hbm_bytes_per_launch'])
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    except (OSError, ValueError):
+        info['refused'] = 'no committed PMC profile for this configuration'
+        return None, info
+    src = source_hash()
+    from degnorm_amd import _lib
+    info['source_sha256'] = src
+    info['profiled_source_sha256'] = d.get('source_sha256')
+    info['lib_sha256_match'] = d.get('lib_sha256') == file_sha256(_lib.LIB_PATH)
+    if d.get('source_sha256') != src:
+        info['refused'] = 'kernel sources changed since the profile was taken'
+        return None, info
+    if d.get('kernel') != kernel_name or int(d.get('genes_in_kernel', -1)) != int(genes_in_kernel):
+        info['refused'] = 'profiled kernel / gene count differ from this run'
+        return None, info
+    info['read_bytes'] = d.get('read_bytes_per_launch')
+    info['write_bytes'] = d.get('write_bytes_per_launch')
+    return float(d['hbm_bytes_per_launch']), info
 
 
-def cpu_baseline(cfg, p, nmf_iter, iters, n_sample):
-    """The CPU oracle (oracle/, parity-pinned port of the reference) timed on this box's host cores."""
+def host_cores():
     from oracle import oracle as orc
-    from degnorm_amd import synth
-    orc.build()
     cores = int(orc.lib().dno_max_threads())
     try:
         cores = max(1, min(cores, len(os.sched_getaffinity(0))))      # the CPUs this process may run on ...
@@ -76,26 +122,78 @@ def cpu_baseline(cfg, p, nmf_iter, iters, n_sample):
             cores = max(1, min(cores, int(float(quota) / float(period))))
     except (OSError, ValueError):
         pass
+    return cores
+
+
+def cpu_baseline(cfg, name, p, nmf_iter, iters, rate, n_sample):
+    """The CPU oracle (oracle/, parity-pinned port of the reference) timed on this box's host cores."""
+    from oracle import oracle as orc
+    from degnorm_amd import synth
+    orc.build()
+    cores = host_cores()
     covs = [synth.synth_gene(cfg['seed'], g, p, cfg['l_min'], cfg['l_max'])[0] for g in range(n_sample)]
     reads = np.vstack([synth.read_counts_from_coverage(c) for c in covs])
+    ds = None
+    if rate > 1:
+        ds = np.random.RandomState(123).randint(0, rate, size=(iters, n_sample)).astype(np.int64)
     t0 = time.time()
-    orc.run(covs, reads, degnorm_iter=iters, nmf_iter=nmf_iter, n_threads=cores)
+    orc.run(covs, reads, degnorm_iter=iters, nmf_iter=nmf_iter, downsample_rate=rate, min_high_coverage=2 if rate > 1 else 50,
+            ds_starts=ds, n_threads=cores)
     dt = time.time() - t0
     return {'value': n_sample / dt, 'unit': 'genes/sec', 'cores': cores, 'kind': 'port',
-            'sample': 'first {0} genes of the config-2 generator, full run ({1} outer iterations, nmf_iter {2}), '
-                      'oracle/nmfoa_oracle.c with OpenMP over genes, {3:.1f} s wall'.format(n_sample, iters, nmf_iter, dt)}
+            'sample': 'first {0} genes of the {1} generator, full run ({2} outer iterations, nmf_iter {3}{4}), '
+                      'oracle/nmfoa_oracle.c with OpenMP over genes, {5:.1f} s wall'
+                      .format(n_sample, name, iters, nmf_iter, ', take-every {0}'.format(rate) if rate > 1 else '', dt)}
+
+
+def parity_check(eng, cfg, p, my_genes, lengths, split, args, rate):
+    """
+    Post-clock value check of the LAST timed step.  For every outer iteration of that step the oracle processes a sample
+    of this rank's genes with the scale factors (and down-sampling offsets) the device used in that iteration; compared:
+    the raw DI rows (relative, BASELINE tolerance 1e-5), ran_baseline_selection flags and the branch trace
+    {n_hi_cov, #nmf calls, sum of active columns, exit code, loop-exit reason, #drops, status} exactly.
+    The sample spans both gene classes and the whole work queue: genes at evenly spaced length quantiles.
+    """
+    from oracle import oracle as orc
+    from degnorm_amd import synth
+    orc.build()
+    n = len(my_genes)
+    k = min(args.parity_genes, n)
+    by_len = np.argsort(lengths, kind='stable')
+    pick = np.unique(by_len[np.linspace(0, n - 1, k).round().astype(int)])
+    covs = [synth.synth_gene(cfg['seed'], my_genes[j], p, cfg['l_min'], cfg['l_max'])[0] for j in pick]
+    prm = orc.make_params(args.nmf_iter, 20, 2 if rate > 1 else 50, rate, False)
+    cores = host_cores()
+    max_rel, max_abs, flips, checked = 0.0, 0.0, 0, 0
+    t0 = time.time()
+    for i in range(len(eng.scale_hist)):
+        ds = eng.offsets_hist[i][pick] if (rate > 1 and eng.offsets_hist[i] is not None) else None
+        rho_o, flags_o, trace_o, _ = orc.baseline_batch(covs, eng.scale_hist[i], prm, ds_start=ds, n_threads=cores)
+        rho_d, flags_d, trace_d = eng.rho_raw_hist[i][pick], eng.flags_hist[i][pick], eng.traces[i][pick]
+        d = np.abs(rho_d - rho_o)
+        max_abs = max(max_abs, float(d.max()))
+        max_rel = max(max_rel, float((d / np.maximum(np.abs(rho_o), 1e-6)).max()))
+        flips += int(np.sum(np.any(trace_d[:, :7] != trace_o[:, :7], axis=1) | (flags_d != flags_o)))
+        checked += len(pick)
+    wide = int(np.sum(lengths[pick] > split)) if split > 0 else len(pick)
+    return {'max_rel_di': max_rel, 'max_abs_di': max_abs, 'branch_flips': flips, 'genes_checked': len(pick),
+            'gene_iterations_checked': checked, 'outer_iterations': len(eng.scale_hist), 'genes_in_wide_class': wide,
+            'tolerance_rel_di': 1e-5, 'ok': bool(flips == 0 and max_rel < 1e-5),
+            'what': 'last timed step; oracle (kind: port, pinned to the reference goldens) given each iteration\'s device-side '
+                    'scale factors; DI rows unclipped; trace[:7] and flags exact', 'oracle_s': time.time() - t0}
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4'])
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--genes', type=int, default=20000, help='total genes (config 2: 20000)')
+    ap.add_argument('--genes', type=int, default=0, help='total genes (default: the configuration\'s: 20000 / 50000)')
     ap.add_argument('--iters', type=int, default=5, help='outer DegNorm iterations per step')
     ap.add_argument('--nmf-iter', type=int, default=100)
-    ap.add_argument('--cpu-sample', type=int, default=768, help='genes in the CPU-baseline sample (0 = skip)')
-    ap.add_argument('--warmup-genes', type=int, default=0, help='0: warm up on the full shard')
+    ap.add_argument('--cpu-sample', type=int, default=-1, help='genes in the CPU-baseline sample (0 = skip; default 768 / 2048)')
+    ap.add_argument('--parity-genes', type=int, default=160, help='genes in the post-clock parity sample (0 = skip)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -114,47 +212,56 @@ def main():
     torch.cuda.set_device(local_rank)
     comm = LocalComm()
     distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ     # under torchrun use RCCL even at N = 1
+    rccl = None
     if distributed:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         comm = TorchComm(device='cuda:{0}'.format(local_rank))
+        rccl = {'backend': dist.get_backend(), 'rccl_ranks': dist.get_world_size(),
+                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version())}
 
-    cfg = dict(synth.CONFIGS['c2'])
+    cfg = dict(synth.CONFIGS[args.config])
     p = cfg['p']
+    rate = 500 if args.config == 'c4' else 1
+    n_genes = args.genes if args.genes > 0 else cfg['n_genes']
     # every rank gets the same total gene length (the generator's lengths are a cheap pure function of the gene id)
-    all_len = [synth.gene_length(cfg['seed'], g, cfg['l_min'], cfg['l_max']) for g in range(args.genes)] if world > 1 else None
-    parts = partition_by_length(all_len, world) if world > 1 else [list(range(args.genes))]
+    all_len = [synth.gene_length(cfg['seed'], g, cfg['l_min'], cfg['l_max']) for g in range(n_genes)] if world > 1 else None
+    parts = partition_by_length(all_len, world) if world > 1 else [list(range(n_genes))]
     my_genes = parts[rank] if rank < len(parts) else []
     t_gen = time.time()
     packed, lengths, reads, _ = synth.synth_packed(cfg['seed'], my_genes, p, cfg['l_min'], cfg['l_max'],
                                                    n_threads=max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
     t_gen = time.time() - t_gen
 
-    eng = ShardedNMFOA(comm=comm, device=local_rank, degnorm_iter=args.iters, nmf_iter=args.nmf_iter)
+    eng = ShardedNMFOA(comm=comm, device=local_rank, degnorm_iter=args.iters, nmf_iter=args.nmf_iter, downsample_rate=rate)
     t_up = time.time()
-    eng.load_packed(packed, lengths, p, reads)
+    eng.load_packed(packed, lengths, p, reads, global_ids=np.asarray(my_genes, dtype=np.int64), n_total=n_genes)
     t_up = time.time() - t_up
+    del packed
 
     def sync():
         torch.cuda.synchronize()
         comm.Barrier()
         torch.cuda.synchronize()
 
+    init_ms = []
+
     def step():
         eng.initialize()
+        init_ms.append(eng.dev.last_init_ms())
         for i in range(args.iters):
             eng.iterate(i, want_estimates=False)
 
     for _ in range(args.warmup):
         step()
 
-    # dominant kernel = the wide-gene class (genes longer than the split length, one 256-thread workgroup per CU)
+    # dominant kernel of c2 = the wide-gene class (genes longer than the split length, one workgroup per CU)
     split = eng.dev.split_length()
     wide = lengths > split if split > 0 else np.ones(len(lengths), dtype=bool)
-    kernel_ms, alg_bytes, alg_all, narrow_ms = [], [], [], []
+    kernel_ms, narrow_ms, all_traces = [], [], []
+    init_ms.clear()
     sync()
     t0 = time.time()
-    all_traces = []
     for _ in range(args.steps):
         step()
         kernel_ms += [c[0] for c in eng.class_ms]
@@ -162,8 +269,6 @@ def main():
         all_traces += eng.traces                                       # accounting happens after the clock stops
     sync()
     dt = time.time() - t0
-    alg_bytes = [algorithmic_bytes(tr, lengths, p, args.nmf_iter, wide) for tr in all_traces]
-    alg_all = [algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in all_traces]
 
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
@@ -171,49 +276,81 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        value = args.genes * args.steps / dt
+        value = n_genes * args.steps / dt
         avg_ms = float(np.mean(kernel_ms))
-        avg_bytes = float(np.mean(alg_bytes))
-        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(eng.dev.class_kernel_name(0), int(wide.sum())) if (world == 1 and args.genes == 20000) else None
-        # fp64 vector work of the inner passes: per column and inner iteration u.a (2p), the update (5p), the Gram
-        # update (p(p+1)) and the 1/s scaling (p) -- the unit that actually bounds the kernel ("What bounds it")
-        col_iters = float(np.mean([float(tr[wide, 2].astype(np.float64).sum()) * args.nmf_iter for tr in all_traces]))
-        flop = col_iters * (p * p + 9.0 * p)
+        name0 = eng.dev.class_kernel_name(0)
         out = {
-            'metric': 'genes/sec (20k genes x 10 samples, 5 iters)',
+            'metric': 'genes/sec (20k genes x 10 samples, 5 iters)' if args.config == 'c2'
+                      else 'genes/sec (50k genes x 50 samples, downsample-grid 500, 5 iters)',
             'value': value, 'unit': 'genes/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'config 2: {0} synthetic genes x {1} samples, L~U[{2},{3}], {4} DegNorm iters, '
-                                   'nmf_iter {5}, fp32 coverage in HBM, fp64 arithmetic'
-                                   .format(args.genes, p, cfg['l_min'], cfg['l_max'], args.iters, args.nmf_iter),
-                       'genes_per_gpu': len(my_genes), 'sharding': 'length-balanced gene partition, 1 all-reduce of 3p+1 f64 per outer iter'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS,
-                         'traffic': traffic,
-                         'traffic_rate_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
-                         'traffic_frac': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         'fp64_valu': {'achieved': flop / (avg_ms * 1e-3) / 1e12, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                       'frac': flop / (avg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                                       'flop_per_column_iteration': p * p + 9.0 * p},
-                         'kernel': eng.dev.class_kernel_name(0), 'avg_launch_ms': avg_ms,
-                         'algorithmic_bytes_per_launch': avg_bytes, 'launches_timed': len(kernel_ms),
-                         'genes_in_kernel': int(wide.sum()), 'split_length': split,
-                         'second_kernel': {'kernel': eng.dev.class_kernel_name(1), 'genes': int((~wide).sum()),
-                                           'algorithmic_bytes_per_launch': float(np.mean(alg_all)) - avg_bytes,
-                                           'launch_to_end_ms': float(np.mean(narrow_ms)),
-                                           'note': 'narrow genes, 128-thread workgroups, fills CUs as the wide class drains'},
-                         'note': 'rank-0 shard; HIP events on the library stream around each launch.  achieved = algorithmic '
-                                 'bytes of SURVEY 8(d) (fp32 x and lambda re-streamed every inner iteration) / time: the kernel keeps '
-                                 'x + lambda of the first ~2000 columns of a gene in LDS, so this figure can exceed the HBM peak; '
-                                 'traffic* = what the fabric-side counters saw'},
-            'setup': {'synth_s': t_gen, 'upload_s': t_up},
+            'config': {'workload': 'config {0}: {1} synthetic genes x {2} samples, L~U[{3},{4}], {5} DegNorm iters, nmf_iter {6}{7}, '
+                                   'fp32 coverage in HBM, fp64 arithmetic'
+                                   .format(2 if args.config == 'c2' else 4, n_genes, p, cfg['l_min'], cfg['l_max'], args.iters,
+                                           args.nmf_iter, ', take-every {0}'.format(rate) if rate > 1 else ''),
+                       'genes_per_gpu': len(my_genes),
+                       'sharding': 'length-balanced gene partition, 1 all-reduce of 3p+3 f64 per outer iter'},
+            'rccl': rccl,
         }
-        if world == 1 and args.cpu_sample > 0:
-            out['cpu_baseline'] = cpu_baseline(cfg, p, args.nmf_iter, args.iters, args.cpu_sample)
+        if args.config == 'c2':
+            alg_wide = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter, wide) for tr in all_traces]))
+            alg_all = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in all_traces]))
+            # fp64 vector work of the inner passes: per column and inner iteration u.a (2p), the update (5p), the Gram
+            # update (p(p+1)) and the 1/s scaling (p); instructions: p(p+1)/2 + 4p FMA/max/mul + p cvt
+            col_iters = float(np.mean([float(tr[wide, 2].astype(np.float64).sum()) * args.nmf_iter for tr in all_traces]))
+            flop = col_iters * (p * p + 9.0 * p)
+            instr = col_iters / 64.0 * (p * (p + 1) / 2.0 + 6.0 * p)              # wave-instructions (64 columns each)
+            tflops = flop / (avg_ms * 1e-3) / 1e12
+            n_cus = 256
+            issue_peak = FP64_VECTOR_PEAK_TFLOPS * 4.0 / FP64_ISSUE_CYCLES_1WAVE
+            traffic, tinfo = pmc_traffic(args.config, name0, int(wide.sum())) if (world == 1 and n_genes == cfg['n_genes']) else (None, {'refused': 'not the profiled shard'})
+            out['roofline'] = {
+                'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': tflops / FP64_VECTOR_PEAK_TFLOPS,
+                'issue_ceiling': {'peak': issue_peak, 'frac': tflops / issue_peak,
+                                  'what': 'one wave per SIMD issues one fp64 FMA per {0} cycles, not 4 (tools/ubench/clock_issue.hip, '
+                                          'in-kernel clock 2.39 GHz; profiles/{1}/ubench_clock_issue.txt)'.format(FP64_ISSUE_CYCLES_1WAVE, ROUND)},
+                'valu_issue_slots': {'wave_instructions': instr, 'slots_frac': instr * 4.0 / (avg_ms * 1e-3 * 2.4e9 * n_cus * 4),
+                                     'what': 'fp64 wave-instructions of the passes x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs)'},
+                'flop_per_column_iteration': p * p + 9.0 * p,
+                'traffic': traffic, 'traffic_info': tinfo,
+                'traffic_rate_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                'traffic_frac_of_hbm_peak': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                'hbm_algorithmic': {'bytes_per_launch': alg_wide, 'rate_gbps': alg_wide / (avg_ms * 1e-3) / 1e9, 'hbm_peak_gbps': HBM_PEAK_GBPS,
+                                    'ratio_to_hbm_peak': alg_wide / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    'what': 'SURVEY 8(d) algorithmic bytes (fp32 x and lambda re-streamed every inner iteration) / kernel time; '
+                                            'NOT a roofline fraction: the kernel keeps x + lambda on chip, so these bytes are mostly never moved'},
+                'kernel': name0, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
+                'genes_in_kernel': int(wide.sum()), 'split_length': split,
+                'second_kernel': {'kernel': eng.dev.class_kernel_name(1), 'genes': int((~wide).sum()),
+                                  'algorithmic_bytes_per_launch': alg_all - alg_wide,
+                                  'launch_to_end_ms': float(np.mean(narrow_ms)),
+                                  'note': 'narrow genes, second stream, runs beside the wide class'},
+                'note': 'rank-0 shard; HIP events on the library streams around each launch'}
         else:
-            out['cpu_baseline'] = None
+            # config 4: after the row-maxima shortcut an outer iteration reads only the sampled columns; the kernel that
+            # streams HBM is the initial ratio-SVD pass over the whole transcripts (nmf.py:109-121, :522-525)
+            init_avg = float(np.mean(init_ms))
+            alg_init = 8.0 * p * float(lengths.sum())                           # init pass 8 p L_g per gene
+            sampled = float(np.mean([tr[:, 0].astype(np.float64).sum() for tr in all_traces]))
+            out['roofline'] = {
+                'bound': 'hbm', 'achieved': alg_init / (init_avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                'frac': alg_init / (init_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'traffic': None,
+                'kernel': eng.dev.init_kernel_name(), 'avg_launch_ms': init_avg, 'launches_timed': len(init_ms),
+                'algorithmic_bytes_per_launch': alg_init,
+                'iteration_kernel': {'kernel': name0, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
+                                     'active_columns_per_launch': sampled,
+                                     'bytes_needed_per_launch': 4.0 * p * float(np.ceil(lengths / float(rate)).sum()),
+                                     'note': 'row maxima once per upload + only the sampled columns are read (SURVEY 8(d) shortcut, declared): '
+                                             'this kernel is bound by the latency of ~100 tiny dependent eigen-solves per nmf() call, not by HBM'},
+                'shortcut': 'max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): per-iteration full-length scans removed; without it SURVEY 8(d) '
+                            'counts 8 p L_g per gene and outer iteration = {0:.3e} B per launch'.format(alg_init),
+                'note': 'rank-0 shard; HIP events on the library stream'}
+        out['setup'] = {'synth_s': t_gen, 'upload_s': t_up}
+        out['parity'] = parity_check(eng, cfg, p, my_genes, lengths, split, args, rate) if args.parity_genes > 0 else None
+        n_cpu = args.cpu_sample if args.cpu_sample >= 0 else (768 if args.config == 'c2' else 2048)
+        out['cpu_baseline'] = cpu_baseline(cfg, args.config, p, args.nmf_iter, args.iters, rate, n_cpu) if (world == 1 and n_cpu > 0) else None
         print(json.dumps(out))
 
     if distributed:

@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdegnorm_amd.so')
+# DN_LIB_PATH: load another build of the SAME library (kernel experiments, tools/variant_ab.sh); never a fallback
+LIB_PATH = os.environ.get('DN_LIB_PATH') or os.path.join(_HERE, 'libdegnorm_amd.so')
 TRACE_LEN = 48
 
 DN_OK = 0
@@ -62,6 +63,10 @@ def load(build_if_missing=False):
     lib.dn_last_kernel_ms.restype = dbl
     lib.dn_main_kernel_name.argtypes = [vp]
     lib.dn_main_kernel_name.restype = c.c_char_p
+    lib.dn_last_init_ms.argtypes = [vp]
+    lib.dn_last_init_ms.restype = dbl
+    lib.dn_init_kernel_name.argtypes = [vp]
+    lib.dn_init_kernel_name.restype = c.c_char_p
     lib.dn_split_length.argtypes = [vp]
     lib.dn_split_length.restype = i32
     lib.dn_class_kernel_ms.argtypes = [vp, c.c_int]
@@ -230,6 +235,12 @@ class Device:
     # -- measurement -------------------------------------------------------------------------------
     def last_kernel_ms(self):
         return float(self.lib.dn_last_kernel_ms(self.h))
+
+    def last_init_ms(self):
+        return float(self.lib.dn_last_init_ms(self.h))
+
+    def init_kernel_name(self):
+        return self.lib.dn_init_kernel_name(self.h).decode()
 
     def main_kernel_name(self):
         return self.lib.dn_main_kernel_name(self.h).decode()

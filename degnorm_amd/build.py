@@ -13,8 +13,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(CSRC, 'obj')
-LIB = os.path.join(HERE, 'libdegnorm_amd.so')
+# DN_BUILD_TAG=<name> (experiments): objects in csrc/obj_<name>, library in build_variants/lib_<name>.so; load it with
+# DN_LIB_PATH=build_variants/lib_<name>.so.  Without a tag: the product library degnorm_amd/libdegnorm_amd.so.
+TAG = os.environ.get('DN_BUILD_TAG', '')
+OBJ = os.path.join(CSRC, 'obj_' + TAG if TAG else 'obj')
+LIB = os.path.join(HERE, '..', 'build_variants', 'lib_{0}.so'.format(TAG)) if TAG else os.path.join(HERE, 'libdegnorm_amd.so')
 P_LIST = list(range(2, int(os.environ.get('DN_P_MAX_TEMPLATED', 64)) + 1))   # keep in sync with DN_FOR_EACH_P in csrc/dn_api.hip
 ARCH = 'gfx950'
 WIDE_NT = int(os.environ.get('DN_WIDE_NT', 256))     # wide-class workgroup size (csrc/dn_api.hip DN_WIDE_NT)
@@ -51,6 +54,7 @@ def _run(cmd):
 def build_library(force=False, verbose=False):
     """Compile and link; returns the path of the shared library."""
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(LIB)), exist_ok=True)
     hipcc = _hipcc()
     hdr = [os.path.join(CSRC, 'dn_kernels.hpp'), os.path.join(CSRC, 'dn_reduce.hpp'), os.path.join(HERE, '..', 'include', 'degnorm_amd.h'),
            os.path.abspath(__file__)]

@@ -172,6 +172,9 @@ struct dn_handle_s {
     double last_scale[dn::P_MAX] = {0};
     bool have_estimate_state = false;
     float last_ms = 0.f;
+    float last_init_ms = 0.f;     // device time of the most recent dn_ratio_svd_sums kernel
+    char init_name[64] = {0};
+    hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr;
     int32_t ds_hint = 1;          // take-every rate the caller intends to use (dn_set_downsample_hint); 1 = none
     int32_t max_steps = dn::EIG_MAX_STEPS_DEFAULT;   // step cap of one eigen-solve (dn_set_solver_step_cap)
     // per-gene counters of the previous dn_baseline_iteration: the narrow class orders its queue by the work they predict
@@ -223,6 +226,8 @@ static int create_streams(dn_handle h)
     HIP_TRY(hipEventCreate(&h->ev2a));
     HIP_TRY(hipEventCreate(&h->ev2b));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&h->ev_i0));
+    HIP_TRY(hipEventCreate(&h->ev_i1));
     return DN_OK;
 }
 
@@ -260,6 +265,8 @@ int dn_destroy(dn_handle h)
     if (h->ev2a) (void) hipEventDestroy(h->ev2a);
     if (h->ev2b) (void) hipEventDestroy(h->ev2b);
     if (h->ev_ready) (void) hipEventDestroy(h->ev_ready);
+    if (h->ev_i0) (void) hipEventDestroy(h->ev_i0);
+    if (h->ev_i1) (void) hipEventDestroy(h->ev_i1);
     if (h->stream2) (void) hipStreamDestroy(h->stream2);
     if (h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
@@ -533,8 +540,10 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     int per_cu = std::max(1, h->ks->blocks_per_cu(1));
     int grid = (int) std::min<int64_t>(h->n, (int64_t) per_cu * h->n_cus);
     if (h->ks->p == 0) grid = std::min(grid, h->slots);          // generic kernels work in the scratch slots
+    HIP_TRY(hipEventRecord(h->ev_i0, h->stream));
     h->ks->init(a, grid, h->stream);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_i1, h->stream));
     const size_t np = (size_t) h->n * h->p;
     HIP_TRY(hipMemcpyAsync(est_sums, h->d_est_sums, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(cov_sums, h->d_cov_sums, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
@@ -542,6 +551,9 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     if (!status) { st_local.resize(h->n); status = st_local.data(); }
     HIP_TRY(hipMemcpyAsync(status, h->d_status, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventElapsedTime(&h->last_init_ms, h->ev_i0, h->ev_i1));
+    if (h->ks->p >= 2 && h->ks->p <= 16) snprintf(h->init_name, sizeof(h->init_name), "k_ratio_svd<%d,%d>", h->ks->p, h->ks->nt);
+    else snprintf(h->init_name, sizeof(h->init_name), "k_ratio_svd_gen");
     return DN_OK;
 }
 
@@ -709,6 +721,8 @@ int dn_fetch_estimates_subset(dn_handle h, int64_t n_sel, const int64_t *gene_id
 }
 
 double dn_last_kernel_ms(dn_handle h) { return h ? (double) h->last_ms : 0.0; }
+double dn_last_init_ms(dn_handle h) { return h ? (double) h->last_init_ms : 0.0; }
+const char *dn_init_kernel_name(dn_handle h) { return h ? h->init_name : ""; }
 const char *dn_main_kernel_name(dn_handle h) { return (h && h->ks) ? h->ks->baseline_name : ""; }
 double dn_class_kernel_ms(dn_handle h, int cls) { return (h && cls >= 0 && cls < 2) ? (double) h->cls[cls].last_ms : 0.0; }
 const char *dn_class_kernel_name(dn_handle h, int cls) { return (h && cls >= 0 && cls < 2 && h->cls[cls].ks && h->cls[cls].n > 0) ? h->cls[cls].ks->baseline_name : ""; }

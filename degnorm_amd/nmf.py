@@ -62,6 +62,7 @@ class GeneNMFOA(object):
 
         self.device = int(os.environ.get('LOCAL_RANK', 0)) if device is None else int(device)
         self.downsample_offsets = None     # optional (degnorm_iter x n_genes) explicit start offsets
+        self.solver_step_cap = None        # optional: step cap of one on-chip eigen-solve (default 4000)
         self.traces = []                   # per outer iteration: (n_genes x TRACE_LEN) int32 device traces
         self.kernel_ms = []                # per outer iteration: device time of the main kernel
         self._dev = None
@@ -115,6 +116,8 @@ class GeneNMFOA(object):
         dev = _lib.Device(self.device)
         self._dev = dev
         dev.hint_downsample(self.downsample_rate)
+        if self.solver_step_cap is not None:
+            dev.set_solver_step_cap(self.solver_step_cap)
         dev.upload(cov_mats, n_threads=max(self.n_jobs, 0))
         if dev.inexact:
             warnings.warn('{0} coverage values are not exactly representable in float32; '
@@ -122,6 +125,10 @@ class GeneNMFOA(object):
 
         # ---- initialisation (nmf.py:521-535) ----
         est_sums, cov_sums, status = dev.ratio_svd_sums()
+        if np.any(status == -4):
+            raise ValueError('the rank-1 SVD did not converge within the step cap on {0} gene(s) during initialisation '
+                             '(ARPACK would raise ArpackNoConvergence): first {1}'
+                             .format(int(np.sum(status == -4)), self.genes[int(np.argmax(status == -4))]))
         if np.any(status != 0):
             raise ValueError('rank-1 SVD failed on {0} gene(s) during initialisation (all-zero coverage?): first {1}'
                              .format(int(np.sum(status != 0)), self.genes[int(np.argmax(status != 0))]))
@@ -151,6 +158,12 @@ class GeneNMFOA(object):
             if np.any(bad):
                 logging.warning('DegNorm iteration {0} -- {1} gene(s) hit a degenerate factorization '
                                 '(reference would raise); their DI scores were left at 0.'.format(i + 1, int(bad.sum())))
+            noconv = np.flatnonzero(trace[:, 6] == -4)
+            if noconv.size:
+                logging.warning('DegNorm iteration {0} -- the rank-1 SVD did not converge within the step cap on {1} gene(s) '
+                                '(ARPACK would raise ArpackNoConvergence); not used, DI left at 0: {2}{3}'
+                                .format(i + 1, noconv.size, ', '.join(self.genes[k] for k in noconv[:10]),
+                                        ' ...' if noconv.size > 10 else ''))
 
             rho[rho > 0.9] = 0.9                                    # nmf.py:398
             rho[rho < 0.] = 0.                                      # nmf.py:399

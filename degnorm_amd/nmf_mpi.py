@@ -173,6 +173,8 @@ class ShardedNMFOA(object):
         self.kernel_ms = []
         self.traces = []
         self.class_ms = []
+        self.scale_hist, self.rho_raw_hist, self.flags_hist, self.n_failed = [], [], [], []
+        self.offsets_hist = []
         self.downsample_offsets = None                    # optional (degnorm_iter x n_local) explicit starts
         self.n_local = 0
         self.n_total = 0
@@ -238,6 +240,8 @@ class ShardedNMFOA(object):
         self.x_adj = None
         self.kernel_ms, self.traces, self.class_ms = [], [], []
         self.n_failed = []
+        self.scale_hist, self.rho_raw_hist, self.flags_hist = [], [], []     # per outer iteration: inputs / raw device outputs
+        self.offsets_hist = []
         return self.scale_factors
 
     def _offsets(self, i):
@@ -256,6 +260,7 @@ class ShardedNMFOA(object):
         """One outer DegNorm iteration on this rank's genes + the per-sample all-reduce."""
         p = self.p
         ds = self._offsets(i)
+        self.offsets_hist.append(ds)
         if self.n_local > 0:
             rho, flags, trace = self.dev.baseline_iteration(
                 self.scale_factors, nmf_iter=self.nmf_iter, bins=self.bins, min_high_coverage=self.min_high_coverage,
@@ -269,6 +274,9 @@ class ShardedNMFOA(object):
             self.kernel_ms.append(0.0)
             self.class_ms.append((0.0, 0.0))
         self.traces.append(trace)
+        self.scale_hist.append(np.copy(self.scale_factors))
+        self.rho_raw_hist.append(np.copy(rho))
+        self.flags_hist.append(np.copy(flags))
         rho[rho > 0.9] = 0.9                                          # nmf.py:398-399
         rho[rho < 0.] = 0.
         self.ran_baseline_selection[:, i] = flags

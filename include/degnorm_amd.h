@@ -128,6 +128,9 @@ const char *dn_assemble_last_error(void);
  * on the library's own stream; kernel name via dn_main_kernel_name().                               */
 double dn_last_kernel_ms(dn_handle h);
 const char *dn_main_kernel_name(dn_handle h);
+/* The same for the most recent dn_ratio_svd_sums (the initial pass over the whole transcripts).       */
+double dn_last_init_ms(dn_handle h);
+const char *dn_init_kernel_name(dn_handle h);
 /* Genes are run in two classes: class 0 = genes longer than dn_split_length() (256-thread workgroups, one per CU),
  * class 1 = the others (128-thread workgroups, two per CU); one kernel launch per class and outer iteration. */
 int32_t dn_split_length(dn_handle h);

@@ -124,6 +124,24 @@ def test_run_config2_subset_vs_reference_golden():
     assert rel.max() < 1e-5
 
 
+def test_run_config2_deep_vs_reference_golden():
+    """
+    The headline configuration at depth: 256 genes x BASELINE's 5 outer iterations x T = 100 against the REAL reference
+    (tests/golden/run_c2_deep.npz, ~17 min of reference time): both gene classes of the device run concurrently,
+    every exit of baseline_selection occurs, the narrow queue is re-ordered by predicted cost from iteration 2 on.
+    """
+    G, m, est = _run_fixture('run_c2_deep')
+    _check_run(G, m, est)
+    assert int(G['degnorm_iter']) == 5
+    L = np.array([e.shape[1] for e in est])
+    split = m._dev.split_length()
+    assert (L > split).sum() >= 64 and (L <= split).sum() >= 64       # both classes well populated
+    exits = np.concatenate([t[:, 3] for t in m.traces])
+    assert set(exits.tolist()) >= {0, 3, 4, 6}
+    rel = np.abs(m.rho - G['rho']) / np.maximum(np.abs(G['rho']), 1e-300)
+    assert rel.max() < 1e-5
+
+
 def test_run_downsampled_vs_reference_golden():
     """take-every 50 with the reference's captured systematic-sample offsets (nmf.py:408-453)."""
     _check_run(*_run_fixture('run_dsamp50'))
@@ -165,6 +183,106 @@ def test_degenerate_genes_report_status_not_crash(device):
     rho, flags, trace = device.baseline_iteration(np.ones(4), nmf_iter=20)
     assert trace[0, 3] == 0 and not flags[0] and np.all(rho[0] == 0)     # no high coverage at all -> defaults
     assert trace[1, 6] == 0
+
+
+def _slow_gene():
+    """Two sample groups with mirrored coverage envelopes: lambda_2 / lambda_1 of the Gram matrix ~ 0.79, so a cold
+    eigen-solve needs ~100 power steps (a config-2 gene needs ~10); 15 nmf() calls, non-zero DI (T = 20)."""
+    rng = np.random.default_rng(9)
+    L = 600
+    eA = np.r_[np.full(L // 2, 200.), np.full(L // 2, 12.)]
+    mean = np.vstack([np.tile(eA, (5, 1)), np.tile(eA[::-1], (5, 1))])
+    return rng.poisson(mean).astype(float)
+
+
+def test_solver_step_cap_is_reported_not_silent(device, oracle):
+    """
+    An eigen-solve that leaves through its step cap must not feed DI scores silently (ARPACK would raise
+    ArpackNoConvergence): with the cap lowered below what a slowly converging matrix (sigma_2 / sigma_1 -> 1) needs, the
+    gene gets status -4, a zero DI row and no flag; with the default cap the same gene converges and matches the oracle.
+    """
+    p = 10
+    base = _slow_gene()
+    easy = synth.synth_gene(2, 3, p, 400, 900)[0]
+    device.upload([base, easy])
+    scale = np.ones(p)
+    rho_ok, flags_ok, tr_ok = device.baseline_iteration(scale, nmf_iter=20)
+    assert tr_ok[0, 6] == 0 and tr_ok[1, 6] == 0
+    prm = oracle.make_params(nmf_iter=20)
+    rho_o, flags_o, tr_o, _ = oracle.baseline_batch([base, easy], scale, prm)
+    np.testing.assert_array_equal(tr_ok[:, :7], tr_o[:, :7])
+    np.testing.assert_allclose(rho_ok, rho_o, rtol=1e-7, atol=1e-9)          # slow convergence: looser than RTOL on the hard gene
+    steps_needed = tr_ok[0, 7] / max(1, tr_ok[0, 1] * 21)
+    assert steps_needed > 16                                                 # the hard gene really needs many steps per solve
+    device.set_solver_step_cap(16)
+    rho_c, flags_c, tr_c = device.baseline_iteration(scale, nmf_iter=20)
+    assert tr_c[0, 6] == -4 and not flags_c[0] and np.all(rho_c[0] == 0)
+    assert tr_c[1, 6] == 0                                                   # the easy gene converges within 16 steps
+    np.testing.assert_allclose(rho_c[1], rho_ok[1], rtol=1e-12)
+    device.set_solver_step_cap(4000)
+
+
+def test_unconverged_genes_are_warned_about(caplog):
+    """GeneNMFOA.run names the genes whose eigen-solve did not converge (status -4) instead of using their vectors."""
+    import logging
+    from collections import OrderedDict
+    from degnorm_amd.nmf import GeneNMFOA
+    p = 10
+    cov = OrderedDict(hard=_slow_gene())
+    for g in range(6):
+        cov['g%d' % g] = synth.synth_gene(2, g, p, 400, 900)[0]
+    reads = np.vstack([synth.read_counts_from_coverage(c) for c in cov.values()])
+    m = GeneNMFOA(degnorm_iter=1, nmf_iter=20)
+    m.solver_step_cap = 16
+    with pytest.raises(ValueError, match='did not converge within the step cap.*hard'):      # already the initial pass says so
+        m.run(cov, reads)
+    # the iterations: let the initial pass run uncapped, then lower the cap
+    from degnorm_amd import _lib
+    plain = _lib.Device.ratio_svd_sums
+
+    def uncapped_init(self):
+        self.set_solver_step_cap(4000)
+        out = plain(self)
+        self.set_solver_step_cap(16)
+        return out
+    _lib.Device.ratio_svd_sums = uncapped_init
+    try:
+        with caplog.at_level(logging.WARNING):
+            m.run(cov, reads)
+    finally:
+        _lib.Device.ratio_svd_sums = plain
+    assert m.traces[0][0, 6] == -4 and np.all(m.traces[0][1:, 6] == 0)
+    assert any('did not converge' in r.getMessage() and 'hard' in r.getMessage() for r in caplog.records)
+
+
+def test_two_handles_on_two_devices():
+    """Each device configures its own dynamic-LDS opt-in (dn_inst.hip launch_baseline): a second GPU must launch too."""
+    from degnorm_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    covs = _genes(2, range(8), 10, 2500, 5000)                                # wide class: > 64 KiB of dynamic LDS
+    out = []
+    for d in (0, 1):
+        dev = _lib.Device(d)
+        dev.upload(covs)
+        out.append(dev.baseline_iteration(np.ones(10), nmf_iter=10))
+        dev.close()
+    np.testing.assert_array_equal(out[0][2][:, :7], out[1][2][:, :7])
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-13)
+
+
+def test_rejected_upload_keeps_the_resident_data_consistent(device):
+    """
+    An upload whose shapes are rejected must not leave new host-side shapes over old device buffers (dn_api.hip
+    check_shape validates into locals and commits only on success): the previous data set keeps working unchanged.
+    """
+    covs = _genes(2, range(4), 10, 300, 600)
+    device.upload(covs)
+    rho1, flags1, trace1 = device.baseline_iteration(np.ones(10), nmf_iter=5)
+    with pytest.raises(ValueError, match='gene length out of range'):
+        device.upload_packed(np.zeros(10, dtype=np.float32), np.array([2, 0]), 5)   # a zero-length gene
+    rho2, flags2, trace2 = device.baseline_iteration(np.ones(10), nmf_iter=5)
+    assert np.array_equal(rho1, rho2) and np.array_equal(trace1[:, :8], trace2[:, :8])
 
 
 def test_full_size_properties_config2(device):
@@ -217,6 +335,69 @@ def test_full_size_properties_config2(device):
         np.testing.assert_allclose(rho_r[::-1], rho_p, rtol=1e-11, atol=1e-13)
         np.testing.assert_array_equal(tr_r[::-1, :7], tr_p[:, :7])
     finally:
+        dev2.close()
+
+
+def test_full_size_properties_config4(device, oracle, monkeypatch):
+    """
+    BASELINE configs[3] at full size: 50 000 genes x 50 samples, L ~ U[501, 5000] (27.5 GB of fp32 coverage in HBM),
+    take-every 500, nmf_iter = 100, one outer iteration after the initial ratio-SVD pass.  The reference needs ~5 h for
+    it, so the batch is checked through size-independent properties:
+      * determinism: two launches give bit-identical DI scores, flags and traces;
+      * the sampled grid: n_hi_cov <= ceil((L - start) / 500) for every gene (nmf.py:223-227);
+      * gene independence: every 97th gene run alone, with its own offsets, gives bit-identical rows and traces -- also
+        on the 256-thread run-time-p family instead of the one-wavefront-per-gene one (DN_FORCE_GENERIC=2);
+      * the first 48 genes agree with the CPU oracle (DI to 1e-9, traces exactly), the initial pass on them as well.
+    """
+    c = synth.CONFIGS['c4']
+    n, p, rate, T = c['n_genes'], c['p'], 500, 100
+    packed, lengths, reads, _ = synth.synth_packed(c['seed'], range(n), p, c['l_min'], c['l_max'], n_threads=16)
+    assert packed.nbytes > 27e9
+    ds = np.random.RandomState(4).randint(0, rate, size=n).astype(np.int64)
+    scale = np.linspace(0.7, 1.4, p)
+    device.hint_downsample(rate)
+    try:
+        device.upload_packed(packed, lengths, p)
+    finally:
+        device.hint_downsample(1)                 # the fixture's device is shared with the other tests
+    est, cov, status = device.ratio_svd_sums()
+    assert not status.any() and np.isfinite(est).all()
+    kw = dict(nmf_iter=T, min_high_coverage=2, downsample_rate=rate)
+    rho1, fl1, tr1 = device.baseline_iteration(scale, ds_start=ds, **kw)
+    rho2, fl2, tr2 = device.baseline_iteration(scale, ds_start=ds, **kw)
+    assert np.array_equal(rho1, rho2) and np.array_equal(fl1, fl2) and np.array_equal(tr1[:, :40], tr2[:, :40])
+    assert np.all(tr1[:, 6] == 0) and np.isfinite(rho1).all()
+    assert np.all(tr1[:, 0] <= (lengths - ds + rate - 1) // rate)
+    assert (tr1[:, 1] > 1).sum() > n // 10 and device.class_kernel_name(0) == 'k_baseline_rows'
+
+    offs = np.concatenate([[0], np.cumsum(lengths * p)])
+    head = np.arange(48)
+    covs = [packed[offs[g]:offs[g + 1]].reshape(p, int(lengths[g])).astype(np.float64) for g in head]
+    prm = oracle.make_params(nmf_iter=T, downsample_rate=rate)
+    rho_o, flags_o, trace_o, _ = oracle.baseline_batch(covs, scale, prm, ds_start=ds[head])
+    np.testing.assert_allclose(rho1[head], rho_o, rtol=RTOL, atol=ATOL)
+    np.testing.assert_array_equal(fl1[head], flags_o)
+    np.testing.assert_array_equal(tr1[head, :7], trace_o[:, :7])
+    est_o, cov_o, _ = oracle.ratio_svd_batch(covs)
+    np.testing.assert_allclose(cov[head], cov_o, rtol=1e-14)
+    np.testing.assert_allclose(est[head], est_o, rtol=1e-10, atol=1e-7)
+
+    sub = np.arange(0, n, 97)
+    sub_packed = np.concatenate([packed[offs[g]:offs[g + 1]] for g in sub])
+    del packed
+    dev2 = type(device)(0)
+    try:
+        for force in (None, '2'):
+            if force:
+                monkeypatch.setenv('DN_FORCE_GENERIC', force)
+            dev2.hint_downsample(rate)
+            dev2.upload_packed(sub_packed, lengths[sub], p)
+            rho_s, fl_s, tr_s = dev2.baseline_iteration(scale, ds_start=ds[sub], **kw)
+            assert dev2.class_kernel_name(0) == ('k_baseline_gen' if force else 'k_baseline_rows')
+            assert np.array_equal(rho_s, rho1[sub]) and np.array_equal(fl_s, fl1[sub])
+            np.testing.assert_array_equal(tr_s[:, :7], tr1[sub, :7])
+    finally:
+        monkeypatch.delenv('DN_FORCE_GENERIC', raising=False)
         dev2.close()
 
 
@@ -425,7 +606,7 @@ def test_downsampled_wide_cohorts_vs_oracle(oracle, p, rate, monkeypatch):
     device = _lib.Device(0)
     device.hint_downsample(rate)                         # <= 12 active columns per gene: the library picks the row-wise kernels
     device.upload(covs)
-    assert device.class_kernel_name(0) == 'k_baseline_gen'
+    assert device.class_kernel_name(0) == ('k_baseline_gen' if rate == 150 else 'k_baseline_rows')   # one wavefront per gene
     rho, flags, trace = device.baseline_iteration(scale, nmf_iter=30, min_high_coverage=2, downsample_rate=rate,
                                                   ds_start=offs, want_estimates=True)
     prm = oracle.make_params(nmf_iter=30, min_high_coverage=2, downsample_rate=rate)
@@ -438,6 +619,32 @@ def test_downsampled_wide_cohorts_vs_oracle(oracle, p, rate, monkeypatch):
         np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8)
     assert trace[:, 0].min() >= 0 and trace[:, 0].max() <= (12 if rate != 150 else 34)
     device.close()
+
+
+def test_wrong_downsample_hint_grows_the_scratch(oracle):
+    """
+    The hint sizes the scratch slots of the one-wavefront-per-gene family; an iteration at a smaller rate than announced
+    (more active columns than the slots hold, and more than nmf_rows takes) must still be right: the slots are re-sized
+    and the block-wide nmf_gen of that family does the work.
+    """
+    from degnorm_amd import _lib
+    rng = np.random.default_rng(78)
+    p, rate = 10, 50
+    covs = [synth.synth_gene(12, g, p, 401, 4000)[0] for g in range(40)]
+    offs = rng.integers(0, rate, size=len(covs)).astype(np.int64)
+    scale = np.linspace(0.9, 1.1, p)
+    dev = _lib.Device(0)
+    dev.hint_downsample(4000)                              # "every gene keeps one column": 64-column slots
+    dev.upload(covs)
+    assert dev.class_kernel_name(0) == 'k_baseline_rows'
+    rho, flags, trace = dev.baseline_iteration(scale, nmf_iter=15, min_high_coverage=2, downsample_rate=rate, ds_start=offs)
+    dev.close()
+    assert trace[:, 0].max() > 64                          # more active columns than the slots were sized for
+    prm = oracle.make_params(nmf_iter=15, min_high_coverage=2, downsample_rate=rate)
+    rho_o, flags_o, trace_o, _ = oracle.baseline_batch(covs, scale, prm, ds_start=offs)
+    np.testing.assert_array_equal(trace[:, [0, 1, 2, 3, 5, 6]], trace_o[:, [0, 1, 2, 3, 5, 6]])
+    np.testing.assert_array_equal(flags, flags_o)
+    np.testing.assert_allclose(rho, rho_o, rtol=1e-8, atol=1e-10)
 
 
 def test_downsample_hint_only_changes_the_kernel_family(device, oracle):
@@ -456,7 +663,7 @@ def test_downsample_hint_only_changes_the_kernel_family(device, oracle):
         rho, flags, trace = dev.baseline_iteration(scale, nmf_iter=25, min_high_coverage=2, downsample_rate=rate, ds_start=offs)
         out.append((rho, flags, trace, dev.class_kernel_name(0)))
         dev.close()
-    assert out[0][3].startswith('k_baseline<10') and out[1][3] == 'k_baseline_gen'
+    assert out[0][3].startswith('k_baseline<10') and out[1][3] == 'k_baseline_rows'
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2][:, [0, 1, 2, 3, 5, 6]], out[1][2][:, [0, 1, 2, 3, 5, 6]])
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-9, atol=1e-11)

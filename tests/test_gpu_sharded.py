@@ -62,3 +62,48 @@ def test_two_ranks_on_the_gpu_match_reference_mpi_golden(partition):
     np.testing.assert_array_equal(res['ran_baseline_selection'], G['mpi2_flags'])
     assert list(res['estimates'].keys()) == list(cov_dat.keys())
     np.testing.assert_allclose(np.vstack(list(res['estimates'].values())), G['mpi2_est_rowsum'], rtol=1e-9)
+
+
+def _nccl_worker(port, out_q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    import torch
+    import torch.distributed as dist
+    from degnorm_amd.nmf_mpi import ShardedNMFOA, TorchComm
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        G, cov_dat = _inputs()
+        comm = TorchComm(device='cuda:0')
+        assert comm.backend == 'nccl' and comm.size == 1
+        probe = comm.allreduce_sum(np.arange(31, dtype=np.float64))            # the 3p+1-sized collective itself, on the device
+        eng = ShardedNMFOA(comm=comm, device=0, degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']))
+        eng.load(list(cov_dat.values()), G['reads'])
+        eng.run(want_estimates=False)
+        comm.Barrier()
+        out_q.put(dict(rho=eng.rho, x_adj=eng.x_adj, flags=eng.ran_baseline_selection, probe=probe,
+                       rccl='.'.join(str(v) for v in torch.cuda.nccl.version())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_driver_over_rccl_world_size_1():
+    """
+    The collective path as the multi-GPU bench runs it -- torch.distributed backend "nccl" (= RCCL on ROCm), float64
+    tensors on the device, TorchComm.allreduce_sum -- at the one world size this box offers; results == the reference's
+    single-node rows of tests/golden/mpi.npz (run_gene_nmfoa_mpi == GeneNMFOA.run there).  Own process: the process group
+    must not outlive the test.
+    """
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out_q = ctx.Queue()
+    proc = ctx.Process(target=_nccl_worker, args=(29500 + ((os.getpid() + 7) % 2000), out_q))
+    proc.start()
+    res = out_q.get(timeout=300)
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    G, _ = _inputs()
+    np.testing.assert_array_equal(res['probe'], np.arange(31, dtype=np.float64))
+    np.testing.assert_allclose(res['rho'], G['single_rho'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res['x_adj'], G['single_x_adj'], rtol=1e-9)
+    np.testing.assert_array_equal(res['flags'], G['single_flags'])
+    assert res['rccl']

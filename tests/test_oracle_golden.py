@@ -111,6 +111,17 @@ def test_run_config2_subset(oracle):
     _check_run(oracle, 'run_c2')
 
 
+def test_run_config2_deep(oracle):
+    """
+    G4 at depth: 256 genes of config 2 (ids disjoint from run_c2), BASELINE's 5 outer iterations, T = 100 -- both device
+    gene classes (L <= / > ~2047) and every exit of baseline_selection; per-iteration call counts and active columns exact.
+    """
+    G, out = _check_run(oracle, 'run_c2_deep')
+    assert int(G['degnorm_iter']) == 5 and len(G['gene_ids']) == 256
+    rel = np.abs(out['rho'] - G['rho']) / np.maximum(np.abs(G['rho']), 1e-300)
+    assert rel.max() < 1e-5                                           # BASELINE.json's stated DI tolerance
+
+
 def test_run_downsampled(oracle):
     """G6: take-every 50 (p=6) and the config-4 regime (p=50, take-every 500, active matrices 50 x <=10)."""
     _check_run(oracle, 'run_dsamp50')

@@ -2,7 +2,9 @@
 Condenses a tools/profile_round.sh output directory into the files kept under profiles/<round>/:
 per-kernel FETCH_SIZE / WRITE_SIZE summaries, the kernel stats, and pmc_traffic.json (HBM-side bytes per launch of the
 dominant kernel, FETCH_SIZE doubled as calibrated in profiles/round1/pmc_calibration_*.csv and prescribed for gfx950 by
-the MI355X guide).  Usage: python tools/pmc_summary.py gpurun_out/<dir> profiles/round1 <prefix>
+the MI355X guide).  The json names the kernel sources (bench.source_hash) and the library binary it was measured
+on; bench.py refuses to report the traffic for any other source tree.
+Usage: python tools/pmc_summary.py gpurun_out/<dir> profiles/round2 <prefix> [config]
 """
 import csv
 import json
@@ -43,6 +45,8 @@ def mean_of(per, needle):
 
 def main():
     src, dst, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
+    config = sys.argv[4] if len(sys.argv) > 4 else 'c2'
+    os.makedirs(dst, exist_ok=True)
     fetch = per_kernel(os.path.join(src, 'fetch', 'run_counter_collection.csv'), 'FETCH_SIZE')
     write = per_kernel(os.path.join(src, 'write', 'run_counter_collection.csv'), 'WRITE_SIZE')
     write_summary(fetch, os.path.join(dst, prefix + 'pmc_fetch_size_per_kernel.csv'))
@@ -66,6 +70,9 @@ def main():
                   'on gfx950 it reports 1/2 of the bytes of coalesced reads -- MI355X guide, and calibrated here with '
                   'tools/ubench/stream_read.hip: 0.500 for 4-B and 8-B-per-lane reads, WRITE_SIZE 1.000)',
         'kernel': name,
+        'config': config,
+        'source_sha256': json.load(open(os.path.join(src, 'hashes.json')))['source_sha256'],
+        'lib_sha256': json.load(open(os.path.join(src, 'hashes.json')))['lib_sha256'],
         'split_length': bench['roofline'].get('split_length'),
         'genes_in_kernel': bench['roofline'].get('genes_in_kernel'),
         'FETCH_SIZE_KiB_per_launch': f_w,
@@ -79,7 +86,7 @@ def main():
         traffic['FETCH_SIZE_KiB_per_launch_narrow_kernel'] = mean_of(fetch, narrow)
         traffic['WRITE_SIZE_KiB_per_launch_narrow_kernel'] = mean_of(write, narrow)
         traffic['hbm_bytes_per_launch_narrow_kernel'] = (2.0 * mean_of(fetch, narrow) + mean_of(write, narrow)) * 1024.0
-    with open(os.path.join(dst, 'pmc_traffic.json'), 'w') as fh:
+    with open(os.path.join(dst, 'pmc_traffic_{0}.json'.format(config)), 'w') as fh:
         json.dump(traffic, fh, indent=1)
     print(json.dumps(traffic, indent=1))
 
