@@ -283,7 +283,7 @@ static int size_class(dn_handle h, dn_handle_s::GeneClass &C, int32_t cols)
     C.slots = (int) std::min<int64_t>(C.n, (int64_t) per_cu * h->n_cus);
     C.S = (cols + 63) & ~63;
     // slot: Fs, Fb (fp32, p x S) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
-    C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double));
+    C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double)) + (int64_t) C.ks->slot_extra_bytes;
     {
         // one very long gene sizes every slot of its class: keep the scratch within a share of free HBM by
         // running fewer persistent workgroups rather than failing

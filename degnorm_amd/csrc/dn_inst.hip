@@ -78,6 +78,7 @@ const KernelSet *DN_CAT3(kernel_set_p, DN_P, _nt, DN_NT)()
         DN_P, DN_NT, launch_baseline, launch_init, launch_est, blocks_per_cu,
         sizeof(Smem<DN_P, DN_NT>) + sizeof(GeneState<DN_P>),
         name,
+        DN_REG_TIER ? rt_save_bytes<DN_P, DN_NT>() : 0,
     };
     return &ks;
 }

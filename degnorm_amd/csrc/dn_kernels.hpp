@@ -1090,11 +1090,129 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
     return ST_OK;
 }
 
-// Out of line on purpose: the call has its own register allocation (Gram accumulators + one column in
-// flight), independent of what the state machine keeps live, so that two waves fit on a SIMD.
+// ---------------------------------------------------------------------------------------------------
+// Register tier of the x + lambda state (narrow cohorts, DN_RT_MIN_P <= p <= DN_RT_MAX_P).
+// At one wave per SIMD a lane owns 512 registers; the pass needs ~250 of them (Gram accumulators, the column in flight,
+// the prefetched counts), the other half sat idle while the state of long genes went out to the fabric (spill tier).
+// Here the kernel is compiled for a budget of 256 registers (__launch_bounds__(NT, 2): the allocator then uses
+// architectural VGPRs only and never touches an accumulation register -- AGPRs: 0 in the resource report of such a
+// build), and ALL 256 AGPRs hold state: column r of lane tid is column tid + r * NT of the gene, its p doubles sit in
+// a[2 p r ...).  They are reached only through the v_accvgpr_read / v_accvgpr_write below, with literal register
+// numbers (the code is unrolled over r); the "a255" clobber in k_baseline makes the kernel descriptor ask for all 512
+// registers, so the hardware still runs one wave per SIMD.  tests/test_host.py checks on the generated ISA that no
+// compiler-generated instruction names an AGPR.
+// Order of the tiers along a gene: registers [0, RT * NT), then LDS, then the spill array.
+// p = 10, 256 threads: 12 x 256 = 3 072 columns in registers + 1 950 in LDS >= the longest config-2 gene.
+// ---------------------------------------------------------------------------------------------------
+#ifndef DN_RT_MAX_COLS
+#define DN_RT_MAX_COLS 12
+#endif
+#ifndef DN_RT_MAX_P
+#define DN_RT_MAX_P 12           // above it the Gram accumulators alone need more than 256 registers
+#endif
+#ifndef DN_RT_MIN_P
+#define DN_RT_MIN_P 8            // below it a workgroup needs so few registers that several share a SIMD: left alone
+#endif
+template <int P> constexpr int rt_cols()
+{
+    return (P >= DN_RT_MIN_P && P <= DN_RT_MAX_P) ? (256 / (2 * P) < DN_RT_MAX_COLS ? 256 / (2 * P) : DN_RT_MAX_COLS) : 0;
+}
+#if defined(DN_P) && DN_P >= DN_RT_MIN_P && DN_P <= DN_RT_MAX_P && !defined(DN_NO_REG_TIER)
+#define DN_REG_TIER 1
+#define DN_KERNEL_WAVES 2        // the register ALLOCATOR's budget: 512 / 2 registers (the kernel really runs one wave per SIMD)
+// The caller's view: nmf_call() visibly uses no AGPR (it must not name one in a constraint or clobber: a function that
+// visibly uses AGPRs gets half of its budget as AGPRs, 128 + 128), so inter-procedural register allocation lets
+// k_baseline park values in accumulation registers across the call.  nmf_call() therefore SAVES the registers of the
+// tier to the workgroup's scratch slot on entry and restores them on every exit (rt_save / rt_restore: 2 x 240 moves
+// and 2 x 120 coalesced 8-byte accesses per lane and call, against >= 100 passes over the gene in between).
+// k_baseline names a255 once so that the kernel descriptor asks for all 512 registers of a lane.
+#define DN_RT_CLAIM() asm volatile("" ::: "a255")
+#else
+#define DN_REG_TIER 0
+#define DN_KERNEL_WAVES DN_MIN_WAVES
+#define DN_RT_CLAIM()
+#endif
+
+// agpr_get<N>() / agpr_put<N>(v): the double held in a[N : N + 1], N even.  Register names must be literal text.
+template <int IDX> __device__ __forceinline__ double agpr_get();
+template <int IDX> __device__ __forceinline__ void agpr_put(double v);
+#define DN_AGPR_ACCESSORS(N, N1)                                                                                          \
+    template <> __device__ __forceinline__ double agpr_get<N>()                                                           \
+    {                                                                                                                     \
+        int lo, hi;                                                                                                       \
+        asm volatile("v_accvgpr_read_b32 %0, a" #N "\n\tv_accvgpr_read_b32 %1, a" #N1 : "=v"(lo), "=v"(hi));             \
+        return __hiloint2double(hi, lo);                                                                                  \
+    }                                                                                                                     \
+    template <> __device__ __forceinline__ void agpr_put<N>(double v)                                                     \
+    {                                                                                                                     \
+        asm volatile("v_accvgpr_write_b32 a" #N ", %0\n\tv_accvgpr_write_b32 a" #N1 ", %1" : : "v"(__double2loint(v)), "v"(__double2hiint(v))); \
+    }
+#define DN_AGPR_PAIRS(X) \
+    X(0, 1) X(2, 3) X(4, 5) X(6, 7) X(8, 9) X(10, 11) X(12, 13) X(14, 15) \
+    X(16, 17) X(18, 19) X(20, 21) X(22, 23) X(24, 25) X(26, 27) X(28, 29) X(30, 31) \
+    X(32, 33) X(34, 35) X(36, 37) X(38, 39) X(40, 41) X(42, 43) X(44, 45) X(46, 47) \
+    X(48, 49) X(50, 51) X(52, 53) X(54, 55) X(56, 57) X(58, 59) X(60, 61) X(62, 63) \
+    X(64, 65) X(66, 67) X(68, 69) X(70, 71) X(72, 73) X(74, 75) X(76, 77) X(78, 79) \
+    X(80, 81) X(82, 83) X(84, 85) X(86, 87) X(88, 89) X(90, 91) X(92, 93) X(94, 95) \
+    X(96, 97) X(98, 99) X(100, 101) X(102, 103) X(104, 105) X(106, 107) X(108, 109) X(110, 111) \
+    X(112, 113) X(114, 115) X(116, 117) X(118, 119) X(120, 121) X(122, 123) X(124, 125) X(126, 127) \
+    X(128, 129) X(130, 131) X(132, 133) X(134, 135) X(136, 137) X(138, 139) X(140, 141) X(142, 143) \
+    X(144, 145) X(146, 147) X(148, 149) X(150, 151) X(152, 153) X(154, 155) X(156, 157) X(158, 159) \
+    X(160, 161) X(162, 163) X(164, 165) X(166, 167) X(168, 169) X(170, 171) X(172, 173) X(174, 175) \
+    X(176, 177) X(178, 179) X(180, 181) X(182, 183) X(184, 185) X(186, 187) X(188, 189) X(190, 191) \
+    X(192, 193) X(194, 195) X(196, 197) X(198, 199) X(200, 201) X(202, 203) X(204, 205) X(206, 207) \
+    X(208, 209) X(210, 211) X(212, 213) X(214, 215) X(216, 217) X(218, 219) X(220, 221) X(222, 223) \
+    X(224, 225) X(226, 227) X(228, 229) X(230, 231) X(232, 233) X(234, 235) X(236, 237) X(238, 239) \
+    X(240, 241) X(242, 243) X(244, 245) X(246, 247) X(248, 249) X(250, 251) X(252, 253) X(254, 255)
+DN_AGPR_PAIRS(DN_AGPR_ACCESSORS)
+#undef DN_AGPR_ACCESSORS
+#undef DN_AGPR_PAIRS
+
+template <int P, int R> __device__ __forceinline__ void rt_read(double (&a)[P])
+{
+    static_for<0, P>([&](auto ic) { constexpr int I = decltype(ic)::value; a[I] = agpr_get<2 * (P * R + I)>(); });
+}
+template <int P, int R> __device__ __forceinline__ void rt_write(const double (&a)[P])
+{
+    static_for<0, P>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put<2 * (P * R + I)>(a[I]); });
+}
+// The caller's contents of the tier's registers, parked in the scratch slot for the duration of one nmf() call:
+// register pair i of lane tid at save[tid * N + i]: lane-major, so that ONE address register and immediate offsets serve
+// all N accesses (register-major would be coalesced but needs N 64-bit addresses, which the compiler keeps alive -- in
+// scratch -- from the save to the restore).
+// Batches of RT_BATCH registers pairs: the loads of a batch are all in flight together (one memory latency per batch, not
+// per register), and the compiler barrier between batches keeps it from gathering every register first (120 doubles
+// would not fit next to anything else).
+constexpr int RT_BATCH = 24;
+template <int N, int NT> __device__ __forceinline__ void rt_save(double *save)
+{
+    static_for<0, (N + RT_BATCH - 1) / RT_BATCH>([&](auto bc) {
+        constexpr int B = decltype(bc)::value * RT_BATCH;
+        constexpr int CNT = (N - B) < RT_BATCH ? (N - B) : RT_BATCH;
+        double v[CNT];
+        static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; v[I] = agpr_get<2 * (B + I)>(); });
+#pragma unroll
+        for (int i = 0; i < CNT; i++) save[(size_t) threadIdx.x * N + B + i] = v[i];
+        asm volatile("" ::: "memory");
+    });
+}
+template <int N, int NT> __device__ __forceinline__ void rt_restore(const double *save)
+{
+    static_for<0, (N + RT_BATCH - 1) / RT_BATCH>([&](auto bc) {
+        constexpr int B = decltype(bc)::value * RT_BATCH;
+        constexpr int CNT = (N - B) < RT_BATCH ? (N - B) : RT_BATCH;
+        double v[CNT];
+#pragma unroll
+        for (int i = 0; i < CNT; i++) v[i] = save[(size_t) threadIdx.x * N + B + i];
+        static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put<2 * (B + I)>(v[I]); });
+        asm volatile("" ::: "memory");
+    });
+}
+template <int P, int NT> constexpr size_t rt_save_bytes() { return (size_t) rt_cols<P>() * P * 8 * NT; }
+
 template <int P, int NT>
-__device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_, double *rs_, double *sv_,
-                                                   int n, int S, int nL, int T, int first_i)
+__device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *rs_, double *sv_,
+                                         int n, int S, int nL, int T, int first_i)
 {
     Smem<P, NT> &sm = g_sm;
     double *lam = g_lam;
@@ -1134,7 +1252,10 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     constexpr int CH = (NG + SW - 1) / SW;
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
     const int tid = threadIdx.x;
-    const int nLe = (n < nL) ? n : nL;                     // end of the LDS tier
+    constexpr int RT = DN_REG_TIER ? rt_cols<P>() : 0;     // columns per lane held in AGPRs (register tier)
+    constexpr int NR = RT * NT;                            // the gene's first NR columns
+    const int nLe = (n < NR + nL) ? n : NR + nL;           // end of the LDS tier (absolute column); LDS slot of column k: k - NR
+    const int kS0 = NR + nL;                               // first column of the spill tier
     if constexpr (P >= DN_MG_MIN_P) {
         const int st = mg_core<P, NT>(Fb, Lg, lam, n, nL, T, u, theta, steps, maxs, noconv);
         if (st != ST_OK) { if (tid == 0) g_gs.status = st; __syncthreads(); return; }
@@ -1182,12 +1303,21 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma unroll
     for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
 
-    for (int k = tid; k < nLe; k += NT) {                       // lmbda = zeros (nmf.py:90): state a = x
+    static_for<0, RT>([&](auto rc) {                             // lmbda = zeros (nmf.py:90): state a = x
+        constexpr int R = decltype(rc)::value;
+        const int k = tid + R * NT;
+        if (k < n) {
+            double f[P];
+            load_f<P>(Fb, k, inv, f);
+            rt_write<P, R>(f);
+        }
+    });
+    for (int k = NR + tid; k < nLe; k += NT) {
         double f[P], a[PS];
         load_f<P>(Fb, k, inv, f);
 #pragma unroll
         for (int i = 0; i < PS; i++) a[i] = i < P ? f[i] : 0.0;
-        lds_col_write<PS>(lam + (size_t) k * PS, a);
+        lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
     }
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
 #pragma clang loop unroll(disable)
@@ -1209,8 +1339,29 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         // latency of the only global read of the tier hides behind ~120 fp64 operations.  Prefetching the fp64 state
         // as well measured 1.7x SLOWER per column -- the extra live registers end up in AGPRs and every use pays a copy
         // -- and so did a register-resident tier in front of it (tools/trace_stats.py, profiles/round1).
+        // register tier: unrolled over the lane's RT columns, the next column's counts requested before this one's arithmetic
+        auto reg_tier = [&]() {
+            if constexpr (RT > 0) {
+                float xq[P];
+                if (tid < n) load_x<P>(Fb, tid, xq);
+                static_for<0, RT>([&](auto rc) {
+                    constexpr int R = decltype(rc)::value;
+                    const int k = tid + R * NT;
+                    if (k < n) {
+                        double f[P], a[P];
+#pragma unroll
+                        for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
+                        if constexpr (R + 1 < RT) load_x<P>(Fb, k + NT < n ? k + NT : k, xq);
+                        rt_read<P, R>(a);
+                        col_update<P>(f, a, u, c);
+                        gram_add_range<P, 0, CH>(G, a);
+                        rt_write<P, R>(a);
+                    }
+                });
+            }
+        };
         auto lds_tier = [&]() {
-            const int first = tid;
+            const int first = NR + tid;
             const int cnt = first < nLe ? (nLe - first + NT - 1) / NT : 0;
             const int step = dir * NT;
             int k = dir > 0 ? first : first + (cnt - 1) * NT;
@@ -1219,7 +1370,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #pragma clang loop unroll(disable)
             for (int j = 0; j < cnt; j++, k += step) {
                 double f[P], a[PS];
-                lds_col_read<PS>(lam + (size_t) k * PS, a);
+                lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
 #pragma unroll
                 for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
                 load_x<P>(Fb, j + 1 < cnt ? k + step : k, xq);      // unconditional (clamped): no branch around the loads
@@ -1230,13 +1381,13 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 gram_add_range<P, 0, CH>(G, aa);
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
-                lds_col_write<PS>(lam + (size_t) k * PS, a);
+                lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
             }
         };
         // spill tier: x + lambda of the columns that do not fit in LDS lives in the slot (L2 / Infinity Cache).
         // Here the loads are far away, and prefetching the next column's counts and state does pay (1.15x).
         auto spill_tier = [&]() {
-            const int first = nL + tid;
+            const int first = kS0 + tid;
             const int cnt = first < n ? (n - first + NT - 1) / NT : 0;
             const int step = dir * NT;
             int k = dir > 0 ? first : first + (cnt - 1) * NT;
@@ -1267,8 +1418,8 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
                 for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], spill_ptr<P>(Lg, k) + i * 64);
             }
         };
-        if (dir > 0) { lds_tier(); spill_tier(); }
-        else { spill_tier(); lds_tier(); }
+        if (dir > 0) { reg_tier(); lds_tier(); spill_tier(); }
+        else { spill_tier(); lds_tier(); reg_tier(); }
         DN_T1(0); }
         { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
         // later sweeps (p >= 16): the remaining Gram entries from the updated state, read-only
@@ -1278,16 +1429,17 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
             gram_t Gq[NQ];
 #pragma unroll
             for (int i = 0; i < NQ; i++) Gq[i] = 0.0;
+            static_assert(SW == 1 || RT == 0, "the later sweeps do not read the register tier");
 #pragma clang loop unroll(disable)
-            for (int k = tid; k < nLe; k += NT) {
+            for (int k = NR + tid; k < nLe; k += NT) {
                 double a[PS], aa[P];
-                lds_col_read<PS>(lam + (size_t) k * PS, a);
+                lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
                 gram_add_range<P, Q * CH, NQ>(Gq, aa);
             }
 #pragma clang loop unroll(disable)
-            for (int k = nL + tid; k < n; k += NT) {
+            for (int k = kS0 + tid; k < n; k += NT) {
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
@@ -1308,22 +1460,35 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     double acc[2 * P + 1];
 #pragma unroll
     for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
-#pragma clang loop unroll(disable)
-    for (int k = tid; k < n; k += NT) {
-        double f[P], l[P], s, r;
+    auto fin = [&](int k, const double (&l)[P]) {
+        double f[P], s, r;
         load_f<P>(Fb, k, inv, f);
+        col_final<P>(f, l, u, first, acc, s, r);
+        rs[k] = r;
+        if (first) sv[k] = s;
+    };
+    static_for<0, RT>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        const int k = tid + R * NT;
+        if (k < n) {
+            double l[P];
+            rt_read<P, R>(l);
+            fin(k, l);
+        }
+    });
+#pragma clang loop unroll(disable)
+    for (int k = NR + tid; k < n; k += NT) {
+        double l[P];
         if (k < nLe) {
             double al[PS];
-            lds_col_read<PS>(lam + (size_t) k * PS, al);
+            lds_col_read<PS>(lam + (size_t) (k - NR) * PS, al);
 #pragma unroll
             for (int i = 0; i < P; i++) l[i] = al[i];
         } else {
 #pragma unroll
             for (int i = 0; i < P; i++) l[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
         }
-        col_final<P>(f, l, u, first, acc, s, r);
-        rs[k] = r;
-        if (first) sv[k] = s;
+        fin(k, l);
     }
     block_sum_lds<2 * P + 1, P, NT, double>(acc, sm);
     for (int e = tid; e < 2 * P + 1; e += NT) g_gs.sums[e] = sm.tot[e];      // 2 p + 1 can exceed the workgroup (p = 64, 128 threads)
@@ -1338,6 +1503,19 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #endif
     }
     __syncthreads();
+}
+
+// Out of line on purpose: the call has its own register allocation (Gram accumulators + one column in flight),
+// independent of what the state machine keeps live.
+template <int P, int NT>
+__device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_, double *rs_, double *sv_, double *rtsave_,
+                                                   int n, int S, int nL, int T, int first_i)
+{
+    constexpr int NSAVE = DN_REG_TIER ? rt_cols<P>() * P : 0;
+    double *rtsave = uniform_ptr(rtsave_);
+    rt_save<NSAVE, NT>(rtsave);
+    nmf_body<P, NT>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+    rt_restore<NSAVE, NT>(rtsave);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1355,7 +1533,7 @@ template <int P> __device__ __forceinline__ double lds_min(const double *v)
   for (int i = 1; i < P; i++) { const double t = v[i]; m = t < m ? t : m; } return m; }
 
 template <int P, int NT>
-__global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
+__global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
 {
     constexpr int W = NT / 64;
     Smem<P, NT> &sm = g_sm;
@@ -1369,6 +1547,8 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
     double *Lg = reinterpret_cast<double *>(Fb + (size_t) P * S);     // x + lambda, spill tier         [S / 64][P][64]
     double *sv = Lg + (size_t) P * S;                                 // s_start                        [S]
     double *rs = sv + S;                                              // residual profile               [S]
+    double *rtsave = rs + 2 * (size_t) S;                             // caller's AGPRs during an nmf() call  [RT * P][NT]
+    DN_RT_CLAIM();
     if (tid < P) gs.inv[tid] = A.inv_scale[tid];
     if (tid == 0) gs.max_steps = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
     for (int t = tid; t < Smem<P, NT>::NX; t += NT) {                  // constants of the eigen-solver (top_eig_mfma)
@@ -1483,7 +1663,7 @@ __global__ __launch_bounds__(NT, DN_MIN_WAVES) void k_baseline(IterArgs A)
                 // One nmf() call per trip: the first on F_start (nmf.py:245), the others inside the
                 // `while max(rho) > 0.1` loop of nmf.py:273-324 after a bin has been dropped.
                 for (;;) {
-                    nmf_call<P, NT>(Fb, Lg, rs, sv, n, S, nL, A.T, first ? 1 : 0);       // results in gs (LDS)
+                    nmf_call<P, NT>(Fb, Lg, rs, sv, rtsave, n, S, nL, A.T, first ? 1 : 0);       // results in gs (LDS)
                     if (gs.status != ST_OK) { status = gs.status; break; }
                     const double *u = gs.u, *sums = gs.sums;
                     const double theta = gs.theta;
@@ -1791,6 +1971,7 @@ struct KernelSet {
     occupancy_fn blocks_per_cu;       // which: 0 baseline (no dynamic LDS), 1 init
     size_t static_lds_bytes;          // static LDS of k_baseline
     const char *baseline_name;
+    size_t slot_extra_bytes;          // per scratch slot, behind the S-sized arrays (register-tier save area)
 };
 
 const KernelSet *kernel_set_for(int p);   // dn_api.hip
