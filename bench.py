@@ -101,12 +101,13 @@ def pmc_traffic(config, kernel_name, genes_in_kernel):
     if d.get('source_sha256') != src:
         info['refused'] = 'kernel sources changed since the profile was taken'
         return None, info
-    if d.get('kernel') != kernel_name or int(d.get('genes_in_kernel', -1)) != int(genes_in_kernel):
+    k = (d.get('kernels') or {}).get(kernel_name)
+    if k is None or int(k.get('genes_in_kernel') or -1) != int(genes_in_kernel):
         info['refused'] = 'profiled kernel / gene count differ from this run'
         return None, info
-    info['read_bytes'] = d.get('read_bytes_per_launch')
-    info['write_bytes'] = d.get('write_bytes_per_launch')
-    return float(d['hbm_bytes_per_launch']), info
+    info['read_bytes'] = k.get('read_bytes_per_launch')
+    info['write_bytes'] = k.get('write_bytes_per_launch')
+    return float(k['hbm_bytes_per_launch']), info
 
 
 def host_cores():
@@ -146,21 +147,24 @@ def cpu_baseline(cfg, name, p, nmf_iter, iters, rate, n_sample):
                       .format(n_sample, name, iters, nmf_iter, ', take-every {0}'.format(rate) if rate > 1 else '', dt)}
 
 
-def parity_check(eng, cfg, p, my_genes, lengths, split, args, rate):
+def parity_sample(lengths, k):
+    """Genes at evenly spaced length quantiles: both gene classes and the whole work queue."""
+    n = len(lengths)
+    by_len = np.argsort(lengths, kind='stable')
+    return np.unique(by_len[np.linspace(0, n - 1, min(k, n)).round().astype(int)])
+
+
+def parity_check(eng, pick, cfg, p, my_genes, lengths, split, args, rate):
     """
     Post-clock value check of the LAST timed step.  For every outer iteration of that step the oracle processes a sample
-    of this rank's genes with the scale factors (and down-sampling offsets) the device used in that iteration; compared:
-    the raw DI rows (relative, BASELINE tolerance 1e-5), ran_baseline_selection flags and the branch trace
-    {n_hi_cov, #nmf calls, sum of active columns, exit code, loop-exit reason, #drops, status} exactly.
-    The sample spans both gene classes and the whole work queue: genes at evenly spaced length quantiles.
+    of this rank's genes (chosen before the clock started; the engine kept their raw device rows) with the scale factors
+    (and down-sampling offsets) the device used in that iteration; compared: the raw DI rows (relative, BASELINE tolerance
+    1e-5), ran_baseline_selection flags and the branch trace {n_hi_cov, #nmf calls, sum of active columns, exit code,
+    loop-exit reason, #drops, status} exactly.
     """
     from oracle import oracle as orc
     from degnorm_amd import synth
     orc.build()
-    n = len(my_genes)
-    k = min(args.parity_genes, n)
-    by_len = np.argsort(lengths, kind='stable')
-    pick = np.unique(by_len[np.linspace(0, n - 1, k).round().astype(int)])
     covs = [synth.synth_gene(cfg['seed'], my_genes[j], p, cfg['l_min'], cfg['l_max'])[0] for j in pick]
     prm = orc.make_params(args.nmf_iter, 20, 2 if rate > 1 else 50, rate, False)
     cores = host_cores()
@@ -169,7 +173,7 @@ def parity_check(eng, cfg, p, my_genes, lengths, split, args, rate):
     for i in range(len(eng.scale_hist)):
         ds = eng.offsets_hist[i][pick] if (rate > 1 and eng.offsets_hist[i] is not None) else None
         rho_o, flags_o, trace_o, _ = orc.baseline_batch(covs, eng.scale_hist[i], prm, ds_start=ds, n_threads=cores)
-        rho_d, flags_d, trace_d = eng.rho_raw_hist[i][pick], eng.flags_hist[i][pick], eng.traces[i][pick]
+        rho_d, flags_d, trace_d = eng.rho_raw_hist[i], eng.flags_hist[i], eng.traces[i][pick]
         d = np.abs(rho_d - rho_o)
         max_abs = max(max_abs, float(d.max()))
         max_rel = max(max_rel, float((d / np.maximum(np.abs(rho_o), 1e-6)).max()))
@@ -255,10 +259,11 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    # dominant kernel of c2 = the wide-gene class (genes longer than the split length, one workgroup per CU)
     split = eng.dev.split_length()
     wide = lengths > split if split > 0 else np.ones(len(lengths), dtype=bool)
-    kernel_ms, narrow_ms, all_traces = [], [], []
+    kernel_ms, narrow_ms, all_traces, eng_span = [], [], [], []
+    pick = parity_sample(lengths, args.parity_genes) if (args.parity_genes > 0 and len(lengths) > 0) else None
+    eng.history_rows = pick
     init_ms.clear()
     sync()
     t0 = time.time()
@@ -266,6 +271,7 @@ def main():
         step()
         kernel_ms += [c[0] for c in eng.class_ms]
         narrow_ms += [c[1] for c in eng.class_ms]
+        eng_span += list(eng.span_ms)
         all_traces += eng.traces                                       # accounting happens after the clock stops
     sync()
     dt = time.time() - t0
@@ -294,39 +300,57 @@ def main():
             'rccl': rccl,
         }
         if args.config == 'c2':
-            alg_wide = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter, wide) for tr in all_traces]))
+            # Two gene classes = two kernels per outer iteration on two streams: class 0 (genes longer than the split length,
+            # 256-thread workgroups, launched first) and class 1 (the others, 128-thread workgroups, two per CU; it takes
+            # over the CUs as class 0 drains, so its launch spans the whole iteration).  The roofline object describes the
+            # kernel with the longer launch; `iteration` puts BOTH kernels' work over the span of the pair.
+            cls_mask = [wide, ~wide]
+            cls_ms = [float(np.mean(kernel_ms)), float(np.mean(narrow_ms))]
+            dom = 0 if cls_ms[0] >= cls_ms[1] else 1
+            oth = 1 - dom
+            mask, avg_ms, name_d = cls_mask[dom], cls_ms[dom], eng.dev.class_kernel_name(dom)
+            span_ms = float(np.mean(eng_span)) if eng_span else max(cls_ms)
+
+            def work(m):
+                # fp64 vector work of the inner passes: per column and inner iteration u.a (2p), the update (5p), the Gram
+                # update (p(p+1)) and the 1/s scaling (p); wave-instructions: p(p+1)/2 + 5p FMA/max/mul + p cvt per 64 columns
+                col_iters = float(np.mean([float(tr[m, 2].astype(np.float64).sum()) * args.nmf_iter for tr in all_traces]))
+                return col_iters * (p * p + 9.0 * p), col_iters / 64.0 * (p * (p + 1) / 2.0 + 6.0 * p)
+            flop_d, instr_d = work(mask)
+            flop_a, instr_a = work(np.ones(len(lengths), dtype=bool))
+            alg_d = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter, mask) for tr in all_traces]))
             alg_all = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in all_traces]))
-            # fp64 vector work of the inner passes: per column and inner iteration u.a (2p), the update (5p), the Gram
-            # update (p(p+1)) and the 1/s scaling (p); instructions: p(p+1)/2 + 4p FMA/max/mul + p cvt
-            col_iters = float(np.mean([float(tr[wide, 2].astype(np.float64).sum()) * args.nmf_iter for tr in all_traces]))
-            flop = col_iters * (p * p + 9.0 * p)
-            instr = col_iters / 64.0 * (p * (p + 1) / 2.0 + 6.0 * p)              # wave-instructions (64 columns each)
-            tflops = flop / (avg_ms * 1e-3) / 1e12
-            n_cus = 256
+            tflops = flop_d / (avg_ms * 1e-3) / 1e12
+            simd_cycles = lambda ms: ms * 1e-3 * 2.4e9 * 256 * 4
             issue_peak = FP64_VECTOR_PEAK_TFLOPS * 4.0 / FP64_ISSUE_CYCLES_1WAVE
-            traffic, tinfo = pmc_traffic(args.config, name0, int(wide.sum())) if (world == 1 and n_genes == cfg['n_genes']) else (None, {'refused': 'not the profiled shard'})
+            traffic, tinfo = pmc_traffic(args.config, name_d, int(mask.sum())) if (world == 1 and n_genes == cfg['n_genes']) else (None, {'refused': 'not the profiled shard'})
             out['roofline'] = {
                 'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tflops / FP64_VECTOR_PEAK_TFLOPS,
                 'issue_ceiling': {'peak': issue_peak, 'frac': tflops / issue_peak,
                                   'what': 'one wave per SIMD issues one fp64 FMA per {0} cycles, not 4 (tools/ubench/clock_issue.hip, '
                                           'in-kernel clock 2.39 GHz; profiles/{1}/ubench_clock_issue.txt)'.format(FP64_ISSUE_CYCLES_1WAVE, ROUND)},
-                'valu_issue_slots': {'wave_instructions': instr, 'slots_frac': instr * 4.0 / (avg_ms * 1e-3 * 2.4e9 * n_cus * 4),
+                'valu_issue_slots': {'wave_instructions': instr_d, 'slots_frac': instr_d * 4.0 / simd_cycles(avg_ms),
                                      'what': 'fp64 wave-instructions of the passes x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs)'},
                 'flop_per_column_iteration': p * p + 9.0 * p,
                 'traffic': traffic, 'traffic_info': tinfo,
                 'traffic_rate_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
                 'traffic_frac_of_hbm_peak': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                'hbm_algorithmic': {'bytes_per_launch': alg_wide, 'rate_gbps': alg_wide / (avg_ms * 1e-3) / 1e9, 'hbm_peak_gbps': HBM_PEAK_GBPS,
-                                    'ratio_to_hbm_peak': alg_wide / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                'hbm_algorithmic': {'bytes_per_launch': alg_d, 'rate_gbps': alg_d / (avg_ms * 1e-3) / 1e9, 'hbm_peak_gbps': HBM_PEAK_GBPS,
+                                    'ratio_to_hbm_peak': alg_d / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                     'what': 'SURVEY 8(d) algorithmic bytes (fp32 x and lambda re-streamed every inner iteration) / kernel time; '
                                             'NOT a roofline fraction: the kernel keeps x + lambda on chip, so these bytes are mostly never moved'},
-                'kernel': name0, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
-                'genes_in_kernel': int(wide.sum()), 'split_length': split,
-                'second_kernel': {'kernel': eng.dev.class_kernel_name(1), 'genes': int((~wide).sum()),
-                                  'algorithmic_bytes_per_launch': alg_all - alg_wide,
-                                  'launch_to_end_ms': float(np.mean(narrow_ms)),
-                                  'note': 'narrow genes, second stream, runs beside the wide class'},
+                'kernel': name_d, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
+                'genes_in_kernel': int(mask.sum()), 'split_length': split,
+                'second_kernel': {'kernel': eng.dev.class_kernel_name(oth), 'genes': int(cls_mask[oth].sum()),
+                                  'avg_launch_ms': cls_ms[oth],
+                                  'algorithmic_bytes_per_launch': alg_all - alg_d,
+                                  'note': 'the other gene class, own stream, runs beside the dominant kernel'},
+                'iteration': {'span_ms': span_ms, 'fp64_tflops': flop_a / (span_ms * 1e-3) / 1e12,
+                              'frac_of_peak': flop_a / (span_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                              'frac_of_issue_ceiling': flop_a / (span_ms * 1e-3) / 1e12 / issue_peak,
+                              'valu_issue_slots_frac': instr_a * 4.0 / simd_cycles(span_ms),
+                              'what': 'both kernels of an outer iteration: all genes\' fp64 work / time from the first launch to the last end'},
                 'note': 'rank-0 shard; HIP events on the library streams around each launch'}
         else:
             # config 4: after the row-maxima shortcut an outer iteration reads only the sampled columns; the kernel that
@@ -348,7 +372,7 @@ def main():
                             'counts 8 p L_g per gene and outer iteration = {0:.3e} B per launch'.format(alg_init),
                 'note': 'rank-0 shard; HIP events on the library stream'}
         out['setup'] = {'synth_s': t_gen, 'upload_s': t_up}
-        out['parity'] = parity_check(eng, cfg, p, my_genes, lengths, split, args, rate) if args.parity_genes > 0 else None
+        out['parity'] = parity_check(eng, pick, cfg, p, my_genes, lengths, split, args, rate) if pick is not None else None
         n_cpu = args.cpu_sample if args.cpu_sample >= 0 else (768 if args.config == 'c2' else 2048)
         out['cpu_baseline'] = cpu_baseline(cfg, args.config, p, args.nmf_iter, args.iters, rate, n_cpu) if (world == 1 and n_cpu > 0) else None
         print(json.dumps(out))

@@ -63,6 +63,8 @@ def load(build_if_missing=False):
     lib.dn_last_kernel_ms.restype = dbl
     lib.dn_main_kernel_name.argtypes = [vp]
     lib.dn_main_kernel_name.restype = c.c_char_p
+    lib.dn_last_span_ms.argtypes = [vp]
+    lib.dn_last_span_ms.restype = dbl
     lib.dn_last_init_ms.argtypes = [vp]
     lib.dn_last_init_ms.restype = dbl
     lib.dn_init_kernel_name.argtypes = [vp]
@@ -235,6 +237,9 @@ class Device:
     # -- measurement -------------------------------------------------------------------------------
     def last_kernel_ms(self):
         return float(self.lib.dn_last_kernel_ms(self.h))
+
+    def last_span_ms(self):
+        return float(self.lib.dn_last_span_ms(self.h))
 
     def last_init_ms(self):
         return float(self.lib.dn_last_init_ms(self.h))

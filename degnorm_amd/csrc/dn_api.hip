@@ -172,6 +172,7 @@ struct dn_handle_s {
     double last_scale[dn::P_MAX] = {0};
     bool have_estimate_state = false;
     float last_ms = 0.f;
+    float last_span_ms = 0.f;     // first launch to last end of the class kernels of the most recent dn_baseline_iteration
     float last_init_ms = 0.f;     // device time of the most recent dn_ratio_svd_sums kernel
     char init_name[64] = {0};
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr;
@@ -363,11 +364,17 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
         const dn::KernelSet *narrow = (h->ks->p != 0) ? dn::kernel_set_narrow(p) : nullptr;
         if (env) h->split_len = atoi(env);
         else if (narrow) {
-            // narrow class = genes up to ~2.1x the columns its workgroups can keep in LDS (measured optimum 2 000-2 200
-            // bases at p = 10, where a 128-thread workgroup holds 975 columns: profiles/round1/README.md)
+            // Narrow class (128-thread workgroups, two genes per CU): its fixed cost per inner iteration (reduce +
+            // eigen-solve, ~3.3 k cycles) is paid by half a CU instead of a whole one, so it wins for every gene it can
+            // keep mostly on chip.  On-chip columns of a narrow workgroup = register tier + LDS tier; measured optimum of
+            // the boundary on config 2 (p = 10: 1 536 + 975 on chip): 3 600-4 000 bases, i.e. ~1.5 x that capacity
+            // (split 2 047 / 2 511 / 3 100 / 3 600 / 4 000 / 4 400 -> 10 950 / 11 130 / 11 430 / 11 540 / 11 520 / 11 260
+            // genes/s).  Without a register tier: ~2.1 x the LDS columns (round 1: 2 000-2 200 at 975 columns).
             const int per_cu_n = std::max(1, narrow->blocks_per_cu(0));
             const int64_t lds_n = (160 * 1024) / per_cu_n - (int64_t) narrow->static_lds_bytes - 256;
-            h->split_len = (int32_t) std::max<int64_t>(0, (int64_t) (2.1 * (double) (lds_n / (8 * (int64_t) (p + (p & 1))))));
+            const int64_t lds_cols_n = std::max<int64_t>(0, lds_n / (8 * (int64_t) (p + (p & 1))));
+            const int64_t reg_cols_n = narrow->slot_extra_bytes / (8 * (int64_t) p);       // RT * NT (the save area has one double per register pair)
+            h->split_len = (int32_t) (reg_cols_n > 0 ? (int64_t) (1.5 * (double) (reg_cols_n + lds_cols_n)) : (int64_t) (2.1 * (double) lds_cols_n));
         }
         if (!narrow) h->split_len = 0;
         if (!env && p >= 25) h->split_len = 0;     // wide cohorts (MFMA Gram): one class measured 3-5 % faster than two
@@ -553,7 +560,7 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipEventElapsedTime(&h->last_init_ms, h->ev_i0, h->ev_i1));
     if (h->ks->p >= 2 && h->ks->p <= 16) snprintf(h->init_name, sizeof(h->init_name), "k_ratio_svd<%d,%d>", h->ks->p, h->ks->nt);
-    else snprintf(h->init_name, sizeof(h->init_name), "k_ratio_svd_gen");
+    else snprintf(h->init_name, sizeof(h->init_name), (h->p >= 17 && !(getenv("DN_INIT_POWER") && getenv("DN_INIT_POWER")[0] == '1')) ? "k_ratio_svd_mg" : "k_ratio_svd_gen");
     return DN_OK;
 }
 
@@ -658,6 +665,13 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     if (h->cls[0].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[0].last_ms, h->ev0, h->ev1));
     if (h->cls[1].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[1].last_ms, h->ev2a, h->ev2b));
     h->last_ms = h->cls[0].n > 0 ? h->cls[0].last_ms : h->cls[1].last_ms;
+    h->last_span_ms = std::max(h->cls[0].last_ms, h->cls[1].last_ms);
+    if (h->cls[0].n > 0 && h->cls[1].n > 0) {
+        float a = 0.f, b = 0.f;                                          // class 1 is launched after class 0: ev0 is the first start
+        HIP_TRY(hipEventElapsedTime(&a, h->ev0, h->ev1));
+        HIP_TRY(hipEventElapsedTime(&b, h->ev0, h->ev2b));
+        h->last_span_ms = std::max(a, b);
+    }
     h->have_estimate_state = prm->want_estimates != 0;
     return DN_OK;
 }
@@ -722,6 +736,7 @@ int dn_fetch_estimates_subset(dn_handle h, int64_t n_sel, const int64_t *gene_id
 
 double dn_last_kernel_ms(dn_handle h) { return h ? (double) h->last_ms : 0.0; }
 double dn_last_init_ms(dn_handle h) { return h ? (double) h->last_init_ms : 0.0; }
+double dn_last_span_ms(dn_handle h) { return h ? (double) h->last_span_ms : 0.0; }
 const char *dn_init_kernel_name(dn_handle h) { return h ? h->init_name : ""; }
 const char *dn_main_kernel_name(dn_handle h) { return (h && h->ks) ? h->ks->baseline_name : ""; }
 double dn_class_kernel_ms(dn_handle h, int cls) { return (h && cls >= 0 && cls < 2) ? (double) h->cls[cls].last_ms : 0.0; }

@@ -614,6 +614,312 @@ __device__ __forceinline__ int top_singular_raw(const float *x, int L, int p)
 
 // Initial DI pass (nmf.py:109-121, :522-525): top left singular vector of the raw coverage, then the clamped and plain
 // row sums in one more pass (per-thread partials of all rows, reduced in tiles).
+// ---------------------------------------------------------------------------------------------------
+// k_ratio_svd_mg: the initial DI pass (nmf.py:109-121, :522-525) for 17 <= p <= 64 in TWO streaming passes over the raw
+// fp32 coverage -- SURVEY 8(d)'s algorithmic 8 p L bytes per gene -- instead of one pass per power step (k_ratio_svd_gen
+// below read a gene ~20 times).
+//   pass 1  Gram matrix G = X X^T of the p x L matrix on the fp64 matrix cores.  v_mfma_f64_16x16x4_f64 contracts over 4
+//           columns; WHICH 4 columns share an instruction does not matter for a sum over all columns, so lane
+//           (i = l & 15, k = l >> 4) loads ONE float4 = columns c0 + 4k .. 4k + 3 of row 16 t + i (64 contiguous bytes
+//           per row and k-group, no transposition), and round m = 0..3 multiplies component m of every lane:
+//           D[t1][t2] += X_t1(:, {c0 + m, c0 + 4 + m, c0 + 8 + m, c0 + 12 + m}) X_t2(...)^T.  The same register is the A
+//           and the B operand.  Row p of the padded matrix is a row of ones, so that G[p][i] = sum_j x_ij: the plain
+//           row sums (cov_sums) fall out of the same products.  Waves take 16-column groups round-robin; their tiles are
+//           added in LDS one wave after the other (fixed order: deterministic).
+//   solve   top eigenvector of the p x p block by shifted power iteration, the matrix in LDS, all 256 threads on one
+//           matrix-vector product (thread = (row, quarter of the columns)), two steps between convergence checks, the
+//           same stopping rule as top_eig_rows.
+//   pass 2  one column per lane: s_j = u . x_j from the p counts of the column (registers), per-lane partial sums of
+//           max(u_i s_j, x_ij) for every row, reduced at the end in tiles of 8.
+// ---------------------------------------------------------------------------------------------------
+constexpr int MG_ROWS = 80;                  // 5 tiles of 16: p <= 64 samples + the row of ones
+constexpr int MG_LD = MG_ROWS + 1;           // LDS row stride in doubles (odd: the column walk of the solver is conflict-light)
+__shared__ double g_mg[MG_ROWS * MG_LD];
+__shared__ double g_mv[2][MG_ROWS];
+
+template <int TR>
+__device__ __forceinline__ void mg_gram_pass(const float *x, int L, int p)
+{
+    constexpr int NTILE = TR * (TR + 1) / 2;
+    constexpr int W = NT / 64;
+    const int lane = lane_id(), w = wave_id();
+    const int li = lane & 15, lk = lane >> 4;
+    dn_double4 acc[NTILE];
+#pragma unroll
+    for (int i = 0; i < NTILE; i++) acc[i] = dn_double4{0.0, 0.0, 0.0, 0.0};
+    // per tile row: where this lane reads (rows >= p read row 0 and are masked afterwards: no branch around the loads)
+    const float *rowp[TR];
+    float keep[TR], fill[TR];
+#pragma unroll
+    for (int t = 0; t < TR; t++) {
+        const int row = 16 * t + li;
+        rowp[t] = x + (size_t) (row < p ? row : 0) * L + 4 * lk;
+        keep[t] = row < p ? 1.0f : 0.0f;
+        fill[t] = row == p ? 1.0f : 0.0f;                                   // the row of ones
+    }
+    auto load_full = [&](int g, dn_f4 (&xf)[TR]) {                          // g < L / 16: all four columns exist
+#pragma unroll
+        for (int t = 0; t < TR; t++) xf[t] = *(const dn_f4u *) (rowp[t] + 16 * g);
+    };
+    auto products = [&](const dn_f4 (&xf)[TR]) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            double xd[TR];
+#pragma unroll
+            for (int t = 0; t < TR; t++) xd[t] = (double) fmaf(xf[t][m], keep[t], fill[t]);   // counts are exact in fp32: x * 1 + 0, or 0 * x + {0, 1}
+            int tix = 0;
+#pragma unroll
+            for (int t1 = 0; t1 < TR; t1++)
+#pragma unroll
+                for (int t2 = 0; t2 <= t1; t2++, tix++)
+                    acc[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[t1], xd[t2], acc[tix], 0, 0, 0);
+        }
+    };
+    const int nfull = L / 16;
+    dn_f4 xa[TR], xb[TR];
+    int g = w;
+    if (g < nfull) load_full(g, xa);
+#pragma clang loop unroll(disable)
+    for (; g < nfull; g += 2 * W) {                                          // ping-pong: the next group's loads fly during the products
+        const bool more = g + W < nfull;
+        if (more) load_full(g + W, xb);
+        products(xa);
+        if (!more) break;
+        if (g + 2 * W < nfull) load_full(g + 2 * W, xa);
+        products(xb);
+    }
+    if ((L & 15) && w == nfull % W) {                                        // the partial last group: guarded element loads
+        dn_f4 xt[TR];
+        const int c = 16 * nfull + 4 * lk;
+#pragma unroll
+        for (int t = 0; t < TR; t++) {
+            const float *src = rowp[t] + 16 * nfull;
+#pragma unroll
+            for (int m = 0; m < 4; m++) xt[t][m] = (c + m < L) ? src[m] : 0.0f;
+        }
+        // columns beyond L must contribute nothing, also to the row of ones
+        float keep_t[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) keep_t[m] = (c + m < L) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            double xd[TR];
+#pragma unroll
+            for (int t = 0; t < TR; t++) xd[t] = (double) (fmaf(xt[t][m], keep[t], fill[t]) * keep_t[m]);
+            int tix = 0;
+#pragma unroll
+            for (int t1 = 0; t1 < TR; t1++)
+#pragma unroll
+                for (int t2 = 0; t2 <= t1; t2++, tix++)
+                    acc[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[t1], xd[t2], acc[tix], 0, 0, 0);
+        }
+    }
+    // tile (t1, t2): register r of lane (c = l & 15, q = l >> 4) holds D[16 t1 + q + 4 r][16 t2 + c]
+    for (int ww = 0; ww < W; ww++) {
+        if (w == ww) {
+            int tix = 0;
+#pragma unroll
+            for (int t1 = 0; t1 < TR; t1++)
+#pragma unroll
+                for (int t2 = 0; t2 <= t1; t2++, tix++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * t1 + lk + 4 * r, col = 16 * t2 + li;
+                        const double v = acc[tix][r];
+                        if (ww == 0) {
+                            g_mg[row * MG_LD + col] = v;
+                            if (t1 != t2) g_mg[col * MG_LD + row] = v;
+                        } else {
+                            g_mg[row * MG_LD + col] += v;
+                            if (t1 != t2) g_mg[col * MG_LD + row] += v;
+                        }
+                    }
+        }
+        __syncthreads();
+    }
+}
+
+// y = (G - mu I) v for the p x p block of g_mg; v in g_mv[src], y to g_mv[dst] and returned for this thread's row.
+__device__ __forceinline__ double mg_matvec(int p, int src, int dst, double mu)
+{
+    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+    double part = 0.0;
+    if (r < p) {
+        const double *row = g_mg + r * MG_LD;
+        for (int j = q; j < p; j += 4) part = fma(row[j], g_mv[src][j], part);
+    }
+    part += dpp_mov<DPP_QX1>(part);
+    part += dpp_mov<DPP_QX2>(part);
+    const double y = (r < p) ? fma(-mu, g_mv[src][r], part) : 0.0;
+    __syncthreads();                                   // every reader of g_mv[dst]'s previous contents is done
+    if (q == 0 && r < MG_ROWS) g_mv[dst][r] = y;
+    __syncthreads();
+    return y;
+}
+
+// block-wide sum of one value per (row) thread group; only threads with q == 0 contribute
+__device__ __forceinline__ double mg_block_sum(double v)
+{
+    double part[TI];
+    part[0] = (threadIdx.x & 3) == 0 ? v : 0.0;
+#pragma unroll
+    for (int r = 1; r < TI; r++) part[r] = 0.0;
+    tile_sum(part);
+    const double s = g_sm.tot[0];
+    __syncthreads();
+    return s;
+}
+
+__device__ __forceinline__ int mg_solve(int p, int maxs, double *u_out)
+{
+    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+    // trace and the first product from the uniform start vector
+    if (q == 0 && r < MG_ROWS) g_mv[0][r] = r < p ? 1.0 / sqrt((double) p) : 0.0;
+    __syncthreads();
+    const double tr = mg_block_sum(r < p ? g_mg[r * MG_LD + r] : 0.0);
+    if (!(tr > 0.0)) return ST_ARPACK;
+    double ul = r < p ? g_mv[0][r] : 0.0;
+    double y = mg_matvec(p, 0, 1, 0.0);
+    const double th = mg_block_sum(ul * y);
+    if (!(th > 0.0)) return ST_ARPACK;
+    double mu = (tr - th) / (double) (p > 1 ? p - 1 : 1);
+    mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
+    double vl = fma(-mu, ul, y);                       // first shifted step, in g_mv[1] unshifted: rewrite it
+    __syncthreads();
+    if (q == 0 && r < MG_ROWS) g_mv[1][r] = vl;
+    __syncthreads();
+    int steps = 1, status = ST_OK;
+    double d2_prev = -1.0;
+    for (;;) {
+        // normalise the iterate in g_mv[1] into g_mv[0], measure the change
+        const double n2 = mg_block_sum(vl * vl);
+        if (!(n2 > 0.0)) { status = ST_ARPACK; break; }
+        const double inv = 1.0 / sqrt(n2);
+        const double un = vl * inv;
+        const double d = un - ul;
+        const double d2 = mg_block_sum(d * d);
+        ul = un;
+        if (q == 0 && r < MG_ROWS) g_mv[0][r] = ul;
+        __syncthreads();
+        if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev)) break;
+        if (steps >= maxs) { status = ST_NO_CONVERGENCE; break; }
+        d2_prev = d2;
+        (void) mg_matvec(p, 0, 1, mu);                 // two plain shifted steps, no normalisation in between
+        vl = mg_matvec(p, 1, 1, mu);
+        steps += 2;
+    }
+    if (q == 0 && r < p) u_out[r] = ul;
+    if (tid == 0) g_st.steps = steps;
+    __syncthreads();
+    return status;
+}
+
+__global__ __launch_bounds__(NT, 2) void k_ratio_svd_mg(InitArgs A)
+{
+    const int tid = threadIdx.x;
+    const int p = A.p;
+    const int maxs = 5 * (A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT);       // plain power steps, like top_singular
+    const int TR = (p + 1 + 15) / 16;
+    for (;;) {
+        if (tid == 0) g_sm.gene = atomicAdd(A.counter, 1);
+        __syncthreads();
+        const int q = g_sm.gene;
+        __syncthreads();
+        if (q >= A.n_genes) break;
+        const int g = A.order[q];
+        const int L = A.glen[g];
+        const float *x = A.cov + A.goff[g];
+        int status = ST_OK;
+        if (L < 2) status = ST_VALUE_ERROR;
+        else {
+            if (TR <= 2) mg_gram_pass<2>(x, L, p);
+            else if (TR == 3) mg_gram_pass<3>(x, L, p);
+            else if (TR == 4) mg_gram_pass<4>(x, L, p);
+            else mg_gram_pass<5>(x, L, p);
+            status = mg_solve(p, maxs, g_st.u);
+        }
+        // pass 2 (nmf.py:117-121, :524-525): est = max(K E, x) summed per row.  The Gram matrix is no longer needed: its
+        // row of ones (the plain row sums) moves to g_st.rsum, and g_mg holds s_j = u . x_j of a chunk of columns, so
+        // that the rows can be walked in tiles of 8 with 8 live accumulators instead of p.
+        if (tid < p) { g_st.rsum[tid] = g_mg[p * MG_LD + tid]; g_st.csum[tid] = 0.0; }
+        __syncthreads();
+        if (status == ST_OK) {
+            constexpr int CHUNK = MG_ROWS * MG_LD;                                  // 6 480 columns of s per chunk
+            double *sj = g_mg;
+            for (int c0 = 0; c0 < L; c0 += CHUNK) {
+                const int c1 = (c0 + CHUNK < L) ? c0 + CHUNK : L;
+                // NC columns per thread and TI rows per step: NC * TI independent loads in flight (a dependent
+                // load -> fma chain over the p rows of one column would pay the memory latency p times)
+                constexpr int NC = 4;
+                for (int k = c0 + tid; k < c1; k += NC * NT) {
+                    int kc[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; c++) kc[c] = (k + c * NT < c1) ? k + c * NT : k;        // clamped: no branch around the loads
+                    double sd[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; c++) sd[c] = 0.0;
+                    for (int i0 = 0; i0 < p; i0 += TI) {
+                        float xv[NC][TI];
+#pragma unroll
+                        for (int r = 0; r < TI; r++) {
+                            const size_t ro = (size_t) (i0 + r < p ? i0 + r : p - 1) * L;
+#pragma unroll
+                            for (int c = 0; c < NC; c++) xv[c][r] = x[ro + kc[c]];
+                        }
+#pragma unroll
+                        for (int r = 0; r < TI; r++) {
+                            const double ur = i0 + r < p ? g_st.u[i0 + r] : 0.0;
+#pragma unroll
+                            for (int c = 0; c < NC; c++) sd[c] = fma(ur, (double) xv[c][r], sd[c]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; c++) if (k + c * NT < c1) sj[k + c * NT - c0] = sd[c];
+                }
+                __syncthreads();
+                for (int i0 = 0; i0 < p; i0 += TI) {
+                    double part[TI];
+#pragma unroll
+                    for (int r = 0; r < TI; r++) part[r] = 0.0;
+                    for (int k = c0 + tid; k < c1; k += NC * NT) {
+                        int kc[NC];
+                        double sk[NC];
+#pragma unroll
+                        for (int c = 0; c < NC; c++) { kc[c] = (k + c * NT < c1) ? k + c * NT : k; sk[c] = sj[kc[c] - c0]; }
+                        float xv[NC][TI];
+#pragma unroll
+                        for (int r = 0; r < TI; r++) {
+                            const size_t ro = (size_t) (i0 + r < p ? i0 + r : p - 1) * L;
+#pragma unroll
+                            for (int c = 0; c < NC; c++) xv[c][r] = x[ro + kc[c]];
+                        }
+#pragma unroll
+                        for (int r = 0; r < TI; r++) {
+                            const double ur = g_st.u[i0 + r < p ? i0 + r : p - 1];
+#pragma unroll
+                            for (int c = 0; c < NC; c++) {
+                                const double v = (double) xv[c][r];
+                                const double ke = ur * sk[c];
+                                const double e = ke < v ? v : ke;                   // est[est < x] = x   nmf.py:119
+                                part[r] += (k + c * NT < c1) ? e : 0.0;
+                            }
+                        }
+                    }
+                    tile_sum(part);
+                    if (tid < TI && i0 + tid < p) g_st.csum[i0 + tid] += g_sm.tot[tid];
+                    __syncthreads();
+                }
+            }
+        }
+        if (tid < p) {
+            A.est_sums[(size_t) g * p + tid] = status == ST_OK ? g_st.csum[tid] : 0.0;
+            A.cov_sums[(size_t) g * p + tid] = status == ST_OK ? g_st.rsum[tid] : 0.0;
+        }
+        if (tid == 0) A.status[g] = status;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_ratio_svd_gen(InitArgs A)
 {
     const int tid = threadIdx.x;
@@ -725,7 +1031,14 @@ static void launch_est(const EstArgs &a, const int32_t *tg, const int32_t *tc, i
     hipLaunchKernelGGL(k_estimates_gen, dim3(n_tiles), dim3(256), 0, s, a, tg, tc);
 }
 #if DN_GEN_NT == 256
-static void launch_init(const InitArgs &a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_ratio_svd_gen, dim3(grid), dim3(NT), 0, s, a); }
+static void launch_init(const InitArgs &a, int grid, hipStream_t s)
+{
+    // 17 <= p <= 64: two passes over the coverage with the Gram matrix on the matrix cores; DN_INIT_POWER=1 keeps the
+    // one-pass-per-power-step kernel (cross-check in the tests); below 17 samples only the tests come here (DN_FORCE_GENERIC)
+    const char *pw = getenv("DN_INIT_POWER");
+    if (a.p >= 17 && !(pw && pw[0] == '1')) hipLaunchKernelGGL(k_ratio_svd_mg, dim3(grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL(k_ratio_svd_gen, dim3(grid), dim3(NT), 0, s, a);
+}
 static int blocks_per_cu(int which)
 {
     int nb = 0;

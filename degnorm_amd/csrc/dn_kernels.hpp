@@ -781,7 +781,7 @@ struct GeneState {
     int32_t steps;       //   power-iteration steps spent (accumulated over the gene's calls)
     int32_t status;
     int32_t max_steps;   // step cap of one eigen-solve (IterArgs::max_steps)
-    long long stamp[4];  // diagnostic builds (DN_STAMP): cycles in pass / reduction / eigen-solver
+    long long stamp[6];  // diagnostic builds (DN_STAMP): cycles in pass / reduction / eigen-solver / whole nmf() calls / final pass / cold start
 };
 
 // The workgroup's LDS objects live at namespace scope so that the out-of-line nmf_call() addresses them with
@@ -1263,6 +1263,9 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     gram_t G[CH];
 
     // cold start: SVD of x itself (nmf.py:88)
+#ifdef DN_STAMP
+    const long long t_cold0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int i = 0; i < CH; i++) G[i] = 0.0;
 #pragma clang loop unroll(disable)
@@ -1320,6 +1323,9 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
     }
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
+#ifdef DN_STAMP
+    stamp[3] += __builtin_amdgcn_s_memtime() - t_cold0;
+#endif
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
 #pragma unroll
@@ -1457,6 +1463,9 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     }   // narrow cohorts
 
     // final pass: K E of the last SVD, its row sums, the clamped row sums and the residual profile.
+#ifdef DN_STAMP
+    const long long t_fin0 = __builtin_amdgcn_s_memtime();
+#endif
     double acc[2 * P + 1];
 #pragma unroll
     for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
@@ -1500,6 +1509,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         g_gs.status = noconv ? ST_NO_CONVERGENCE : ST_OK;
 #ifdef DN_STAMP
         g_gs.stamp[0] += stamp[0]; g_gs.stamp[1] += stamp[1]; g_gs.stamp[2] += stamp[2];
+        g_gs.stamp[4] += __builtin_amdgcn_s_memtime() - t_fin0; g_gs.stamp[5] += stamp[3];
 #endif
     }
     __syncthreads();
@@ -1513,9 +1523,15 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 {
     constexpr int NSAVE = DN_REG_TIER ? rt_cols<P>() * P : 0;
     double *rtsave = uniform_ptr(rtsave_);
+#ifdef DN_STAMP
+    const long long t_call0 = __builtin_amdgcn_s_memtime();
+#endif
     rt_save<NSAVE, NT>(rtsave);
     nmf_body<P, NT>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     rt_restore<NSAVE, NT>(rtsave);
+#ifdef DN_STAMP
+    if (threadIdx.x == 0) g_gs.stamp[3] += __builtin_amdgcn_s_memtime() - t_call0;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1577,7 +1593,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
 #endif
         int32_t *tr = A.trace + (size_t) g * TRACE_LEN;
         if (tid < P) { gs.rho[tid] = 0.0; gs.K[tid] = 0.0; gs.us[tid] = 0.0; }
-        if (tid == 0) { gs.steps = 0; gs.stamp[0] = gs.stamp[1] = gs.stamp[2] = 0; }
+        if (tid == 0) { gs.steps = 0; gs.stamp[0] = gs.stamp[1] = gs.stamp[2] = gs.stamp[3] = gs.stamp[4] = gs.stamp[5] = 0; }
 
         // ---- get_high_coverage_idx (nmf.py:66-76) on F = x / s (nmf.py:146) -------------------------
         // max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): division by a positive scalar is monotone, so the global maximum
@@ -1830,6 +1846,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
 #ifdef DN_STAMP
             // diagnostic build only: kilo-cycles spent in the pass / reduction / eigen-solver / whole gene
             tr[40] = (int32_t) (gs.stamp[0] >> 10); tr[41] = (int32_t) (gs.stamp[1] >> 10); tr[42] = (int32_t) (gs.stamp[2] >> 10);
+            tr[44] = (int32_t) (gs.stamp[3] >> 10); tr[45] = (int32_t) (gs.stamp[4] >> 10); tr[46] = (int32_t) (gs.stamp[5] >> 10);
             tr[43] = (int32_t) ((__builtin_amdgcn_s_memtime() - t_gene0) >> 10);
 #endif
         }

@@ -173,8 +173,10 @@ class ShardedNMFOA(object):
         self.kernel_ms = []
         self.traces = []
         self.class_ms = []
+        self.span_ms = []
         self.scale_hist, self.rho_raw_hist, self.flags_hist, self.n_failed = [], [], [], []
         self.offsets_hist = []
+        self.history_rows = None                          # optional: local gene rows whose raw DI / flags are kept per iteration
         self.downsample_offsets = None                    # optional (degnorm_iter x n_local) explicit starts
         self.n_local = 0
         self.n_total = 0
@@ -238,7 +240,7 @@ class ShardedNMFOA(object):
         self.ran_baseline_selection = np.zeros((self.n_local, self.degnorm_iter), dtype=bool)
         self._rng = np.random.RandomState(self.random_state)
         self.x_adj = None
-        self.kernel_ms, self.traces, self.class_ms = [], [], []
+        self.kernel_ms, self.traces, self.class_ms, self.span_ms = [], [], [], []
         self.n_failed = []
         self.scale_hist, self.rho_raw_hist, self.flags_hist = [], [], []     # per outer iteration: inputs / raw device outputs
         self.offsets_hist = []
@@ -269,14 +271,16 @@ class ShardedNMFOA(object):
             self.kernel_ms.append(self.dev.last_kernel_ms())
             if hasattr(self.dev, 'class_kernel_ms'):
                 self.class_ms.append((self.dev.class_kernel_ms(0), self.dev.class_kernel_ms(1)))
+                self.span_ms.append(self.dev.last_span_ms())
         else:
             rho, flags, trace = np.zeros((0, p)), np.zeros(0, dtype=bool), np.zeros((0, _lib.TRACE_LEN), dtype=np.int32)
             self.kernel_ms.append(0.0)
             self.class_ms.append((0.0, 0.0))
         self.traces.append(trace)
         self.scale_hist.append(np.copy(self.scale_factors))
-        self.rho_raw_hist.append(np.copy(rho))
-        self.flags_hist.append(np.copy(flags))
+        if self.history_rows is not None:                             # raw device outputs of a few genes (bench.py's parity check)
+            self.rho_raw_hist.append(np.copy(rho[self.history_rows]))
+            self.flags_hist.append(np.copy(flags[self.history_rows]))
         rho[rho > 0.9] = 0.9                                          # nmf.py:398-399
         rho[rho < 0.] = 0.
         self.ran_baseline_selection[:, i] = flags

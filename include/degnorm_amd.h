@@ -135,6 +135,8 @@ const char *dn_init_kernel_name(dn_handle h);
  * class 1 = the others (128-thread workgroups, two per CU); one kernel launch per class and outer iteration. */
 int32_t dn_split_length(dn_handle h);
 double dn_class_kernel_ms(dn_handle h, int cls);
+/* First launch to last end of the class kernels of the most recent dn_baseline_iteration (they overlap).          */
+double dn_last_span_ms(dn_handle h);
 const char *dn_class_kernel_name(dn_handle h, int cls);
 int  dn_synchronize(dn_handle h);
 /* Stream-copy ceiling of this device (GB/s, float4 copy of `bytes` bytes, best of `reps`).          */

@@ -39,6 +39,8 @@ from degnorm.nmf import GeneNMFOA            # noqa: E402  (the reference)
 import degnorm.nmf_mpi as ref_mpi            # noqa: E402
 from degnorm.utils import split_into_chunks  # noqa: E402
 from degnorm_amd import synth                # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import _fixtures                             # noqa: E402
 
 
 def checksum(cov):
@@ -304,7 +306,7 @@ def sec_warm():
     seed, n_genes, p, l_min, l_max, minimax = 5, 60, 6, 200, 1500, 5
     src = tempfile.mkdtemp(prefix='dn_warm_src_')
     out = tempfile.mkdtemp(prefix='dn_warm_out_')
-    synth.write_warm_start_dir(src, seed=seed, n_genes=n_genes, p=p, l_min=l_min, l_max=l_max)
+    _fixtures.write_warm_start_dir(src, seed=seed, n_genes=n_genes, p=p, l_min=l_min, l_max=l_max)
     dat = load_from_previous(src, out)
     gene_cov_dict, read_count_df, genes_df, sample_ids = dat['gene_cov_dict'], dat['read_count_df'], dat['genes_df'], dat['sample_ids']
     loaded_order = list(gene_cov_dict.keys())
@@ -347,7 +349,7 @@ def sec_merge():
         np.float_ = np.float64
     from degnorm.reads_coverage_merge import merge_chrom_coverage
     d = tempfile.mkdtemp(prefix='dn_merge_')
-    sample_ids, exon_df = synth.write_chrom_coverage_dir(d)
+    sample_ids, exon_df = _fixtures.write_chrom_coverage_dir(d)
     out = merge_chrom_coverage(d, sample_ids, exon_df, verbose=False)
     genes = list(out.keys())
     np.savez_compressed(os.path.join(HERE, 'merge.npz'), genes=np.array(genes), sample_ids=np.array(sample_ids),

@@ -1,19 +1,20 @@
 """
 SURVEY 8(f-3): coverage-matrix assembly.  Golden tests/golden/merge.npz = the reference's merge_chrom_coverage
-(reads_coverage_merge.py:167-372) on the synthetic directory of degnorm_amd.synth.write_chrom_coverage_dir.
+(reads_coverage_merge.py:167-372) on the synthetic directory of tests/_fixtures.py write_chrom_coverage_dir.
 The interval logic runs on CPU; the device gather needs the GPU.  Coverage is integer counts: comparisons are exact.
 """
 import numpy as np
 import pytest
 
 from conftest import golden
-from degnorm_amd import synth
+from degnorm_amd import synth  # noqa: F401
+import _fixtures
 from degnorm_amd.coverage_merge import gene_intervals, merge_chrom_coverage, assemble_chrom_packed
 
 
 def test_gene_order_and_exon_unions_match_reference(tmp_path):
     G = golden('merge')
-    sample_ids, exon_df = synth.write_chrom_coverage_dir(str(tmp_path / 'cov'))
+    sample_ids, exon_df = _fixtures.write_chrom_coverage_dir(str(tmp_path / 'cov'))
     assert sample_ids == list(G['sample_ids'])
     genes, ivs = gene_intervals(exon_df)
     assert genes == list(G['genes'])                                   # reference order: sorted by gene_end (:264-267)
@@ -26,7 +27,7 @@ def test_gene_order_and_exon_unions_match_reference(tmp_path):
 def test_device_assembly_matches_reference_exactly(tmp_path):
     G = golden('merge')
     d = str(tmp_path / 'cov')
-    sample_ids, exon_df = synth.write_chrom_coverage_dir(d)
+    sample_ids, exon_df = _fixtures.write_chrom_coverage_dir(d)
     out = merge_chrom_coverage(d, sample_ids, exon_df, verbose=False)
     assert list(out.keys()) == list(G['genes'])
     o = 0

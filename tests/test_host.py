@@ -135,3 +135,62 @@ def test_save_results_files(tmp_path):
     assert sorted(d) == ['g0', 'g2'] and d['g2'][0, 0] == 0 and d['g0'][0, 0] == 1
     with open(tmp_path / 'chr2' / 'estimated_coverage_matrices_chr2.pkl', 'rb') as f:
         assert list(pickle.load(f)) == ['g1']
+
+
+@pytest.mark.parametrize('p,nt', [(10, 256), (10, 128), (12, 128)])
+def test_register_tier_registers_are_private(tmp_path, p, nt):
+    """
+    The register tier (csrc/dn_kernels.hpp) keeps x + lambda in AGPRs through inline v_accvgpr moves with literal register
+    numbers, behind the compiler's back.  That is only sound if (1) the compiler itself never allocates an accumulation
+    register inside nmf_call (its budget there is 256 architectural VGPRs), (2) nmf_call saves and restores every tier
+    register around its body -- the kernel may park values in AGPRs across the call -- and (3) the kernel descriptor asks
+    for all 512 registers of a lane.  Checked on the ISA hipcc generates for the headline sample counts.
+    """
+    import re
+    import subprocess
+    from degnorm_amd import build
+    src = os.path.join(ROOT, 'degnorm_amd', 'csrc', 'dn_inst.hip')
+    out = str(tmp_path / 'k.s')
+    cmd = [build._hipcc()] + build.FLAGS + build.SCHED + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt), '-S', '--cuda-device-only', src, '-o', out]
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    fn, inasm = None, False
+    compiler_agpr = {}          # function -> instructions outside inline asm that name an AGPR
+    tier_regs = {}              # function -> AGPR numbers named inside inline asm
+    for line in open(out):
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            fn = m.group(1)
+        t = line.strip()
+        if t.startswith(';;#ASMSTART'):
+            inasm = True
+            continue
+        if t.startswith(';;#ASMEND'):
+            inasm = False
+            continue
+        if not t or t[0] in ';.':
+            continue
+        code = t.split(';')[0]
+        regs = [int(x) for x in re.findall(r'\ba(\d+)\b', code)] + [int(x) for pair in re.findall(r'\ba\[(\d+):(\d+)\]', code) for x in pair]
+        if not regs:
+            continue
+        if inasm:
+            tier_regs.setdefault(fn, set()).update(regs)
+        else:
+            compiler_agpr[fn] = compiler_agpr.get(fn, 0) + 1
+    call = [f for f in tier_regs if 'nmf_call' in f]
+    assert len(call) == 1 and all('nmf_call' in f for f in tier_regs)          # the tier is touched in nmf_call only
+    n_tier = (256 // (2 * p) if 256 // (2 * p) < 12 else 12) * 2 * p
+    assert tier_regs[call[0]] == set(range(n_tier))                             # a0 .. a(2 p RT - 1), all of them
+    assert compiler_agpr.get(call[0], 0) == 0                                   # (1)
+    text = open(out).read()
+    body = text[text.index(call[0] + ':'):]
+    body = body[:body.index('s_setpc_b64')]
+    blocks = [b for b in re.findall(r';;#ASMSTART(.*?);;#ASMEND', body, flags=re.S) if 'v_accvgpr' in b]
+    n_pairs = n_tier // 2
+    assert all('v_accvgpr_read_b32' in b for b in blocks[:n_pairs])            # (2) entry: every tier register is read (saved) first ...
+    assert all('v_accvgpr_write_b32' in b for b in blocks[-n_pairs:])          # ... and written back (restored) last
+    saved = set(int(x) for b in blocks[:n_pairs] for x in re.findall(r'\ba(\d+)\b', b))
+    restored = set(int(x) for b in blocks[-n_pairs:] for x in re.findall(r'\ba(\d+)\b', b))
+    assert saved == restored == set(range(n_tier))
+    kern = text[text.index('.amdhsa_kernel _ZN2dn10k_baseline'):]
+    assert re.search(r'\.amdhsa_next_free_vgpr 512\b', kern[:4000]) and re.search(r'\.amdhsa_accum_offset 256\b', kern[:4000])   # (3)

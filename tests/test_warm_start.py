@@ -11,13 +11,14 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from degnorm_amd import synth
+from degnorm_amd import synth  # noqa: F401
+import _fixtures
 from degnorm_amd.warm_start import load_from_previous, select_genes, run_from_warm_start
 
 
 def _make_dir(tmp_path, G):
     src = str(tmp_path / 'prev_run')
-    sample_ids = synth.write_warm_start_dir(src, seed=int(G['seed']), n_genes=int(G['n_genes']), p=int(G['p']),
+    sample_ids = _fixtures.write_warm_start_dir(src, seed=int(G['seed']), n_genes=int(G['n_genes']), p=int(G['p']),
                                             l_min=int(G['l_min']), l_max=int(G['l_max']))
     assert sample_ids == list(G['sample_ids'])
     return src

@@ -60,32 +60,35 @@ def main():
     shutil.copy(os.path.join(src, 'bench.json'), os.path.join(dst, prefix + 'bench.json'))
 
     bench = json.load(open(os.path.join(src, 'bench.json')))
-    name = bench['roofline']['kernel']                               # e.g. k_baseline<10,256>
-    wide = spaced(name)
-    narrow_name = bench['roofline'].get('second_kernel', {}).get('kernel', '')
-    f_w, w_w = mean_of(fetch, wide), mean_of(write, wide)
+    hashes = json.load(open(os.path.join(src, 'hashes.json')))
     traffic = {
         'method': 'tools/profile_round.sh: rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py '
-                  '--warmup 0 --cpu-sample 0 (separate passes for FETCH_SIZE and WRITE_SIZE; values in KiB; FETCH_SIZE doubled: '
-                  'on gfx950 it reports 1/2 of the bytes of coalesced reads -- MI355X guide, and calibrated here with '
-                  'tools/ubench/stream_read.hip: 0.500 for 4-B and 8-B-per-lane reads, WRITE_SIZE 1.000)',
-        'kernel': name,
+                  '--warmup 0 --cpu-sample 0 --parity-genes 0 (separate passes for FETCH_SIZE and WRITE_SIZE; values in KiB; FETCH_SIZE '
+                  'doubled: on gfx950 it reports 1/2 of the bytes of coalesced reads -- MI355X guide, and calibrated in round 1 with '
+                  'tools/ubench/stream_read.hip: 0.500 for 4-B and 8-B-per-lane reads, WRITE_SIZE 1.000).  Fabric-side counters: '
+                  'Infinity-Cache hits are included.',
         'config': config,
-        'source_sha256': json.load(open(os.path.join(src, 'hashes.json')))['source_sha256'],
-        'lib_sha256': json.load(open(os.path.join(src, 'hashes.json')))['lib_sha256'],
+        'source_sha256': hashes['source_sha256'],
+        'lib_sha256': hashes['lib_sha256'],
         'split_length': bench['roofline'].get('split_length'),
-        'genes_in_kernel': bench['roofline'].get('genes_in_kernel'),
-        'FETCH_SIZE_KiB_per_launch': f_w,
-        'WRITE_SIZE_KiB_per_launch': w_w,
-        'read_bytes_per_launch': 2.0 * f_w * 1024.0,
-        'write_bytes_per_launch': w_w * 1024.0,
-        'hbm_bytes_per_launch': 2.0 * f_w * 1024.0 + w_w * 1024.0,
+        'kernels': {},
     }
-    if narrow_name:
-        narrow = spaced(narrow_name)
-        traffic['FETCH_SIZE_KiB_per_launch_narrow_kernel'] = mean_of(fetch, narrow)
-        traffic['WRITE_SIZE_KiB_per_launch_narrow_kernel'] = mean_of(write, narrow)
-        traffic['hbm_bytes_per_launch_narrow_kernel'] = (2.0 * mean_of(fetch, narrow) + mean_of(write, narrow)) * 1024.0
+    names = [(bench['roofline'].get('kernel'), bench['roofline'].get('genes_in_kernel'))]
+    for key in ('second_kernel', 'iteration_kernel'):
+        k = bench['roofline'].get(key)
+        if k and k.get('kernel'):
+            names.append((k['kernel'], k.get('genes')))
+    for name, genes in names:
+        if not name:
+            continue
+        rp = spaced(name) if '<' in name else name
+        f_k, w_k = mean_of(fetch, rp), mean_of(write, rp)
+        traffic['kernels'][name] = {
+            'genes_in_kernel': genes,
+            'FETCH_SIZE_KiB_per_launch': f_k, 'WRITE_SIZE_KiB_per_launch': w_k,
+            'read_bytes_per_launch': 2.0 * f_k * 1024.0, 'write_bytes_per_launch': w_k * 1024.0,
+            'hbm_bytes_per_launch': 2.0 * f_k * 1024.0 + w_k * 1024.0,
+        }
     with open(os.path.join(dst, 'pmc_traffic_{0}.json'.format(config)), 'w') as fh:
         json.dump(traffic, fh, indent=1)
     print(json.dumps(traffic, indent=1))

@@ -47,3 +47,18 @@ if tr[:, 40:44].any():
         m = ok & (n0 >= a) & (n0 < b)
         if m.any():
             print('  [%4d,%4d): %5d  %7.0f  %7.0f   %.3f' % (a, b, m.sum(), np.median(per_col[m]), np.median(per_it[m]), tr[m, 43].sum() / tot))
+if tr[:, 44:47].any():
+    ext = tr[:, 44:47].astype(float).sum(axis=0) * 1024
+    tot = tr[:, 43].astype(float).sum() * 1024
+    inner = tr[:, 40:43].astype(float).sum() * 1024
+    print('share of gene time: pass+reduce+eigen %.3f | nmf() calls %.3f (cold start %.3f, final pass %.3f, save/restore+rest %.3f) | outside nmf() %.3f'
+          % (inner / tot, ext[0] / tot, ext[2] / tot, ext[1] / tot, (ext[0] - inner - ext[1] - ext[2]) / tot, 1 - ext[0] / tot))
+    # utilisation of the resident workgroups: sum of per-gene cycles / (slots x kernel wall)
+    for c in (0, 1):
+        ms = dev.class_kernel_ms(c)
+        if ms <= 0:
+            continue
+        m = (lengths > dev.split_length()) if c == 0 else (lengths <= dev.split_length())
+        slots = 256 if c == 0 else 512
+        busy = tr[m, 43].astype(float).sum() * 1024
+        print('class %d: %d genes, sum of gene cycles %.3e = %.1f ms x %d slots at 2.4 GHz (kernel %.1f ms)' % (c, m.sum(), busy, busy / slots / 2.4e6, slots, ms))
