@@ -78,6 +78,9 @@ def load(build_if_missing=False):
     lib.dn_synchronize.argtypes = [vp]
     lib.dn_measure_copy_gbps.argtypes = [vp, i64, c.c_int]
     lib.dn_measure_copy_gbps.restype = dbl
+    lib.dn_assemble_coverage.argtypes = [c.c_int, i64, i32, P(i64), P(vp), P(vp), i64, P(i64), i64, P(i32), P(i64), P(i64), P(i32),
+                                         P(c.c_float), P(dbl)]
+    lib.dn_assemble_last_error.restype = c.c_char_p
     lib.dn_num_genes.argtypes = [vp]
     lib.dn_num_genes.restype = i64
     lib.dn_num_samples.argtypes = [vp]

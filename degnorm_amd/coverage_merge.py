@@ -111,13 +111,6 @@ def assemble_chrom_packed(data_dir, sample_ids, chrom_exon_df, device=None, verb
         logging.warning('{0} coverage values are not exactly representable in float32.'.format(inexact))
 
     lib = _lib.load()
-    lib.dn_assemble_coverage.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
-                                         ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
-                                         ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64,
-                                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64),
-                                         ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32),
-                                         ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
-    lib.dn_assemble_last_error.restype = ctypes.c_char_p
     iptrs = (ctypes.c_void_p * p)(*[a.ctypes.data if a.size else None for a in keep_i])
     vptrs = (ctypes.c_void_p * p)(*[a.ctypes.data if a.size else None for a in keep_v])
     packed = np.empty(int((lengths * p).sum()), dtype=np.float32)

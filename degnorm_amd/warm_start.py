@@ -8,7 +8,16 @@ On-disk layout read here (written by the reference at `reads_coverage_merge.py:4
     <dir>/read_counts.csv                 columns chr, gene, <sample ids...>
     <dir>/<chr>/coverage_matrices_<chr>.pkl   pickled dict {gene: (p x L) float64 ndarray}
 
+Optional packed side-car (written by `write_sidecars`, never by the reference; ignored when stale):
+    <dir>/<chr>/coverage_matrices_<chr>.f32.npy       the chromosome's matrices back to back as float32 -- the layout the
+                                                      device consumes (gene g: p rows of L_g, genes in pickle order)
+    <dir>/<chr>/coverage_matrices_<chr>.f32.idx.npz   gene names, lengths, p, size / mtime of the pickle it was made from
+Unpickling 4 GB of float64 dominates a warm start of a human data set; the side-car is half the bytes, memory-mapped, and
+hands out float32 views that the uploader copies without conversion (profiles/round2/warm_start_load.txt).
+
     python -m degnorm_amd.warm_start --warm-start-dir DIR -o OUT [--iter 5 --nmf-iter 100 -d 1 -s --minimax-coverage 0]
+    python -m degnorm_amd.warm_start --warm-start-dir DIR --write-sidecars
+    python -m torch.distributed.run --nproc-per-node N -m degnorm_amd.warm_start --mpi --warm-start-dir DIR -o OUT ...
 """
 import argparse
 import gc
@@ -21,12 +30,75 @@ from collections import OrderedDict
 import numpy as np
 
 
-def load_from_previous(degnorm_dir, new_dir=None):
+def _sidecar_paths(degnorm_dir, chrom):
+    base = os.path.join(degnorm_dir, str(chrom), 'coverage_matrices_{0}'.format(chrom))
+    return base + '.pkl', base + '.f32.npy', base + '.f32.idx.npz'
+
+
+def write_sidecars(degnorm_dir, chroms=None):
+    """
+    Write the packed float32 side-car of every `<chr>/coverage_matrices_<chr>.pkl` under `degnorm_dir` (once per
+    DegNorm output directory; later warm starts read it instead of the pickle).  Returns {chrom: number of values that
+    float32 cannot hold exactly} -- 0 for DegNorm's integer coverage counts (reads.py:714,773).
+    """
+    if chroms is None:
+        chroms = sorted(d for d in os.listdir(degnorm_dir)
+                        if os.path.isfile(_sidecar_paths(degnorm_dir, d)[0]))
+    out = dict()
+    for chrom in chroms:
+        pkl_file, npy_file, idx_file = _sidecar_paths(degnorm_dir, chrom)
+        with open(pkl_file, 'rb') as f:
+            cov_dat = pkl.load(f)
+        genes = list(cov_dat.keys())
+        lengths = np.array([cov_dat[g].shape[1] for g in genes], dtype=np.int64)
+        p = int(cov_dat[genes[0]].shape[0]) if genes else 0
+        packed = np.lib.format.open_memmap(npy_file, mode='w+', dtype=np.float32, shape=(int(p * lengths.sum()),))
+        o, inexact = 0, 0
+        for g, L in zip(genes, lengths):
+            m = np.asarray(cov_dat[g])
+            blk = packed[o:o + p * int(L)].reshape(p, int(L))
+            blk[...] = m
+            inexact += int(np.count_nonzero(blk != m))
+            o += p * int(L)
+        packed.flush()
+        del packed
+        st = os.stat(pkl_file)
+        np.savez(idx_file, genes=np.array(genes, dtype=str), lengths=lengths, p=p, inexact=inexact,
+                 pkl_size=st.st_size, pkl_mtime_ns=st.st_mtime_ns)
+        out[chrom] = inexact
+    return out
+
+
+def _load_chrom(degnorm_dir, chrom, use_sidecar):
+    """{gene: p x L matrix} of one chromosome: float32 views into the memory-mapped side-car when it is present and was
+    made from the pickle that is there now, else the unpickled float64 dict."""
+    pkl_file, npy_file, idx_file = _sidecar_paths(degnorm_dir, chrom)
+    if use_sidecar and os.path.isfile(npy_file) and os.path.isfile(idx_file):
+        idx = np.load(idx_file)
+        st = os.stat(pkl_file)
+        if int(idx['pkl_size']) == st.st_size and int(idx['pkl_mtime_ns']) == st.st_mtime_ns:
+            if int(idx['inexact']):
+                logging.warning('{0}: {1} coverage values are not exactly representable in float32.'.format(npy_file, int(idx['inexact'])))
+            packed = np.load(npy_file, mmap_mode='r')
+            p = int(idx['p'])
+            out, o = OrderedDict(), 0
+            for g, L in zip(idx['genes'].tolist(), idx['lengths'].tolist()):
+                out[g] = packed[o:o + p * L].reshape(p, L)
+                o += p * L
+            return out
+        logging.info('{0} is stale (the pickle changed): ignored.'.format(npy_file))
+    with open(pkl_file, 'rb') as f:
+        return pkl.load(f)
+
+
+def load_from_previous(degnorm_dir, new_dir=None, use_sidecar=True):
     """
     Same contract as the reference's `load_from_previous` (warm_start.py:10-106): returns a dict with
     `gene_cov_dict` (OrderedDict gene -> p x L matrix, genes in per-chromosome pickle order),
     `read_count_df` and `genes_df` (rows in that same gene order) and `sample_ids`.
     When `new_dir` is given the three inputs are copied there like the reference does.
+    `use_sidecar` (extra): read `coverage_matrices_<chr>.f32.npy` instead of the pickle when it is up to date; the
+    matrices are then float32 (exact for coverage counts) views of a memory map.
     """
     from pandas import read_csv
 
@@ -53,8 +125,7 @@ def load_from_previous(degnorm_dir, new_dir=None):
         if new_dir is not None:
             os.makedirs(os.path.join(new_dir, str(chrom)))
             shutil.copy(cov_file, os.path.join(new_dir, str(chrom), 'coverage_matrices_{0}.pkl'.format(chrom)))
-        with open(cov_file, 'rb') as f:
-            cov_dat = pkl.load(f)
+        cov_dat = _load_chrom(degnorm_dir, chrom, use_sidecar)
         for gene in cov_dat:
             if gene in keep_set:
                 gene_cov_dict[gene] = cov_dat[gene]
@@ -114,10 +185,47 @@ def run_from_warm_start(warm_start_dir, output_dir, degnorm_iter=5, nmf_iter=100
     return model
 
 
+def run_from_warm_start_mpi(comm, warm_start_dir, output_dir, degnorm_iter=5, nmf_iter=100, downsample_rate=1,
+                            skip_baseline_selection=False, minimax_coverage=0, device=None, partition='balanced'):
+    """
+    The `degnorm_mpi --warm-start-dir` chain (`__main_mpi__.py:357-456`) on one process per GPU: rank 0 reads the previous
+    run and applies the MPI CLI's gene filter (minimax coverage, take-every size, and its 9-megabase / 2^31 limits,
+    :374-376); run_gene_nmfoa_mpi ships every rank its packed share once (the reference has every worker unpickle the
+    WHOLE dictionary from a temporary file, :402-415); rank 0 writes the result files (:450-456).  A failure on rank 0
+    before the run (missing files, no genes left) is raised on every rank.  Returns the result dict on rank 0, else None.
+    """
+    from .nmf_mpi import run_gene_nmfoa_mpi, save_results, _bcast
+    err, cov, reads, genes_df, sample_ids = None, None, None, None, None
+    if comm.rank == 0:
+        try:
+            dat = load_from_previous(warm_start_dir, output_dir)
+            cov, reads_df, genes_df = select_genes(dat['gene_cov_dict'], dat['read_count_df'], dat['genes_df'],
+                                                   minimax_coverage=minimax_coverage, downsample_rate=downsample_rate,
+                                                   mpi_limits=True)
+            sample_ids = dat['sample_ids']
+            reads = reads_df[sample_ids].values.astype(np.float64)            # __main_mpi__.py:430
+            logging.info('DegNorm will run on {0} genes, downsampling rate = 1 / {1}, {2} baseline selection.'
+                         .format(len(cov), downsample_rate, 'without' if skip_baseline_selection else 'with'))
+        except (IOError, OSError, ValueError, KeyError) as e:
+            err = '{0}: {1}'.format(type(e).__name__, e)
+    err = _bcast(comm, err)
+    if err is not None:
+        raise ValueError('warm start failed on rank 0 -- ' + err)
+    res = run_gene_nmfoa_mpi(comm, cov, reads, degnorm_iter=degnorm_iter, nmf_iter=nmf_iter, downsample_rate=downsample_rate,
+                             skip_baseline_selection=skip_baseline_selection, device=device, partition=partition)
+    if comm.rank == 0:
+        save_results(genes_df, estimates=res['estimates'], rho=res['rho'], x_adj=res['x_adj'],
+                     ran_baseline_selection=res['ran_baseline_selection'], sample_ids=sample_ids, output_dir=output_dir)
+    comm.Barrier()
+    return res
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description='NMF-OA core of DegNorm from a warm-start directory (MI355X)')
     ap.add_argument('--warm-start-dir', required=True)
-    ap.add_argument('-o', '--output-dir', required=True)
+    ap.add_argument('-o', '--output-dir', default=None)
+    ap.add_argument('--write-sidecars', action='store_true', help='only write the packed float32 side-cars of the directory')
+    ap.add_argument('--mpi', action='store_true', help='one process per GPU under torch.distributed.run (degnorm_mpi counterpart)')
     ap.add_argument('--iter', type=int, default=5)
     ap.add_argument('--nmf-iter', type=int, default=100)
     ap.add_argument('-d', '--downsample-rate', type=int, default=1)
@@ -126,6 +234,32 @@ def main(argv=None):
     ap.add_argument('--device', type=int, default=None)
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format='%(asctime)s ---- %(message)s')
+    if args.write_sidecars:
+        print(write_sidecars(args.warm_start_dir))
+        return
+    if args.output_dir is None:
+        ap.error('-o/--output-dir is required')
+    if args.mpi:
+        import torch
+        import torch.distributed as dist
+        from .nmf_mpi import TorchComm
+        local_rank = int(os.environ.get('LOCAL_RANK', 0))
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl' if use_gpu else 'gloo',
+                                **({'device_id': torch.device('cuda', local_rank)} if use_gpu else {}))
+        try:
+            comm = TorchComm()
+            if comm.rank == 0:
+                os.makedirs(args.output_dir, exist_ok=True)
+            comm.Barrier()
+            run_from_warm_start_mpi(comm, args.warm_start_dir, args.output_dir, degnorm_iter=args.iter, nmf_iter=args.nmf_iter,
+                                    downsample_rate=args.downsample_rate, skip_baseline_selection=args.skip_baseline_selection,
+                                    minimax_coverage=args.minimax_coverage, device=args.device if args.device is not None else local_rank)
+        finally:
+            dist.destroy_process_group()
+        return
     os.makedirs(args.output_dir, exist_ok=True)
     run_from_warm_start(args.warm_start_dir, args.output_dir, degnorm_iter=args.iter, nmf_iter=args.nmf_iter,
                         downsample_rate=args.downsample_rate, skip_baseline_selection=args.skip_baseline_selection,
