@@ -58,6 +58,11 @@ def load(build_if_missing=False):
     lib.dn_ratio_svd_sums.argtypes = [vp, P(dbl), P(dbl), P(i32)]
     lib.dn_baseline_iteration.argtypes = [vp, P(dbl), P(Params), P(i64), P(dbl), P(i32), P(i32)]
     lib.dn_fetch_estimates.argtypes = [vp, P(dbl)]
+    lib.dn_outer_begin.argtypes = [vp, P(dbl), i32]
+    lib.dn_outer_partials.argtypes = [vp, P(dbl)]
+    lib.dn_outer_apply.argtypes = [vp, P(dbl), P(dbl), i32]
+    lib.dn_fetch_outer.argtypes = [vp, P(dbl), P(dbl), P(dbl), P(c.c_uint8)]
+    lib.dn_fetch_rows.argtypes = [vp, i64, P(i64), P(dbl), P(i32)]
     lib.dn_fetch_estimates_subset.argtypes = [vp, i64, P(i64), P(dbl)]
     lib.dn_last_kernel_ms.argtypes = [vp]
     lib.dn_last_kernel_ms.restype = dbl
@@ -182,15 +187,18 @@ class Device:
         return est, cov, status
 
     def baseline_iteration(self, scale, nmf_iter=100, bins=20, min_high_coverage=50, downsample_rate=1,
-                           skip_baseline_selection=False, want_estimates=False, ds_start=None, want_trace=True):
-        """Returns (rho n x p unclipped, flags bool n, trace n x TRACE_LEN int32 or None)."""
+                           skip_baseline_selection=False, want_estimates=False, ds_start=None, want_trace=True, fetch=True):
+        """
+        Returns (rho n x p unclipped, flags bool n, trace n x TRACE_LEN int32 or None).  fetch=False leaves the DI rows and
+        flags on the device (outer_partials / outer_apply / fetch_outer work on them there) and returns (None, None, trace).
+        """
         scale = np.ascontiguousarray(scale, dtype=np.float64)
         if scale.shape != (self.p,):
             raise ValueError('scale must have one entry per sample')
         prm = Params(int(nmf_iter), int(bins), int(min_high_coverage), int(downsample_rate),
                      int(bool(skip_baseline_selection)), int(bool(want_estimates)))
-        rho = np.zeros((self.n, self.p))
-        flags = np.zeros(self.n, dtype=np.int32)
+        rho = np.zeros((self.n, self.p)) if fetch else None
+        flags = np.zeros(self.n, dtype=np.int32) if fetch else None
         trace = np.zeros((self.n, TRACE_LEN), dtype=np.int32) if want_trace else None
         dsp = None
         if ds_start is not None:
@@ -199,9 +207,43 @@ class Device:
                 raise ValueError('ds_start must have one entry per gene')
             dsp = _p(ds_arr, ctypes.c_int64)
         _check(self.lib.dn_baseline_iteration(self.h, _p(scale, ctypes.c_double), ctypes.byref(prm), dsp,
-                                              _p(rho, ctypes.c_double), _p(flags, ctypes.c_int32),
+                                              _p(rho, ctypes.c_double) if fetch else None, _p(flags, ctypes.c_int32) if fetch else None,
                                               _p(trace, ctypes.c_int32) if want_trace else None))
-        return rho, flags.astype(bool), trace
+        return rho, (flags.astype(bool) if fetch else None), trace
+
+    # -- the outer update on the device (dn_outer_*) ---------------------------------------------------
+    def outer_begin(self, x_weighted, degnorm_iter):
+        xw = np.ascontiguousarray(x_weighted, dtype=np.float64)
+        if xw.shape != (self.n, self.p):
+            raise ValueError('x_weighted must be n x p')
+        self._n_iter = int(degnorm_iter)
+        _check(self.lib.dn_outer_begin(self.h, _p(xw, ctypes.c_double), int(degnorm_iter)))
+
+    def outer_partials(self):
+        out = np.zeros(3 * self.p + 3)
+        _check(self.lib.dn_outer_partials(self.h, _p(out, ctypes.c_double)))
+        return out
+
+    def outer_apply(self, avg_di, norm, it):
+        norm = np.ascontiguousarray(norm, dtype=np.float64)
+        avg = None if avg_di is None else np.ascontiguousarray(avg_di, dtype=np.float64)
+        _check(self.lib.dn_outer_apply(self.h, None if avg is None else _p(avg, ctypes.c_double), _p(norm, ctypes.c_double), int(it)))
+
+    def fetch_outer(self):
+        """(rho, x_adj, x_weighted, ran_baseline_selection n x degnorm_iter bool) as the device holds them."""
+        rho, x_adj, xw = np.empty((self.n, self.p)), np.empty((self.n, self.p)), np.empty((self.n, self.p))
+        ran = np.zeros((self.n, self._n_iter), dtype=np.uint8)
+        _check(self.lib.dn_fetch_outer(self.h, _p(rho, ctypes.c_double), _p(x_adj, ctypes.c_double), _p(xw, ctypes.c_double),
+                                       _p(ran, ctypes.c_uint8)))
+        return rho, x_adj, xw, ran.astype(bool)
+
+    def fetch_rows(self, rows):
+        """Raw (unclipped) DI rows and flags of a few genes of the last baseline_iteration."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        rho = np.empty((rows.size, self.p))
+        flags = np.zeros(rows.size, dtype=np.int32)
+        _check(self.lib.dn_fetch_rows(self.h, rows.size, _p(rows, ctypes.c_int64), _p(rho, ctypes.c_double), _p(flags, ctypes.c_int32)))
+        return rho, flags.astype(bool)
 
     def fetch_estimates_subset(self, gene_ids):
         """Estimates of the chosen genes only (indices in upload order): list of (p x L_g) float64 arrays."""

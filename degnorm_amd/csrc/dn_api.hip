@@ -96,6 +96,106 @@ __global__ __launch_bounds__(256) void k_row_max(const float *__restrict__ cov, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The outer DegNorm update on the device (nmf.py:398-399, :148-158, :575-590; nmf_mpi.py:821-838).  Per outer iteration
+// the host needs 3p + 3 numbers, not the n x p DI matrix: one wave per gene, lane i = sample i.
+//   k_outer_partials  clip rho to [0, 0.9]; untouched = (max_i rho == 0); per-sample partial sums
+//                     A = sum_touched x_w / (1 - rho), B = sum_untouched x_w, W = sum x_w; counts of untouched / failed /
+//                     unconverged genes.  Block partials, then k_outer_reduce adds them in block order (deterministic).
+//   k_outer_apply     rho[untouched] = avg_di; x_adj = x_w / (1 - rho); x_w /= norm; ran_baseline_selection[:, iter].
+// ---------------------------------------------------------------------------------------------------
+constexpr int OUT_BLOCKS = 512;
+constexpr int OUT_STRIDE = 3 * 64 + 4;          // per block: A[64] B[64] W[64] n_untouched n_failed n_noconv (pad)
+
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_outer_partials(const double *__restrict__ rho_raw, double *__restrict__ rho_c,
+                                                        const double *__restrict__ xw, const int32_t *__restrict__ trace,
+                                                        double *__restrict__ part, int n, int p)
+{
+    __shared__ double sm[4][3][64];
+    __shared__ double cnt[4][3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    double a = 0.0, b = 0.0, ws = 0.0, nu = 0.0, nf = 0.0, nc = 0.0;
+    for (int g = blockIdx.x * 4 + w; g < n; g += nw) {
+        double r = 0.0, x = 0.0;
+        if (lane < p) {
+            r = rho_raw[(size_t) g * p + lane];
+            r = r > 0.9 ? 0.9 : r;                                        // nmf.py:398
+            r = r < 0.0 ? 0.0 : r;                                        // nmf.py:399
+            rho_c[(size_t) g * p + lane] = r;
+            x = xw[(size_t) g * p + lane];
+        }
+        const bool untouched = wave_max_d(r) == 0.0;                      // nmf.py:155
+        a += untouched ? 0.0 : x / (1.0 - r);                             // nmf.py:575
+        b += untouched ? x : 0.0;
+        ws += x;
+        if (lane == 0) {
+            const int st = trace[(size_t) g * dn::TRACE_LEN + 6];
+            nu += untouched ? 1.0 : 0.0; nf += st != 0 ? 1.0 : 0.0; nc += st == dn::ST_NO_CONVERGENCE ? 1.0 : 0.0;
+        }
+    }
+    sm[w][0][lane] = a; sm[w][1][lane] = b; sm[w][2][lane] = ws;
+    if (lane == 0) { cnt[w][0] = nu; cnt[w][1] = nf; cnt[w][2] = nc; }
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int k = threadIdx.x >> 6, i = threadIdx.x & 63;
+        part[(size_t) blockIdx.x * OUT_STRIDE + 64 * k + i] = ((sm[0][k][i] + sm[1][k][i]) + sm[2][k][i]) + sm[3][k][i];
+    } else if (threadIdx.x < 195) {
+        const int k = threadIdx.x - 192;
+        part[(size_t) blockIdx.x * OUT_STRIDE + 192 + k] = ((cnt[0][k] + cnt[1][k]) + cnt[2][k]) + cnt[3][k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_outer_reduce(const double *__restrict__ part, double *__restrict__ out, int nblocks, int p)
+{
+    const int t = threadIdx.x;
+    if (t >= 195) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; b++) s += part[(size_t) b * OUT_STRIDE + t];
+    const int k = t >> 6, i = t & 63;
+    if (t < 192) { if (i < p) out[k * p + i] = s; }
+    else out[3 * p + (t - 192)] = s;
+}
+
+__global__ __launch_bounds__(256) void k_outer_apply(double *__restrict__ rho_c, double *__restrict__ xw, double *__restrict__ xadj,
+                                                     const int32_t *__restrict__ flags, uint8_t *__restrict__ ran,
+                                                     const double *__restrict__ avg_di, const double *__restrict__ norm,
+                                                     int have_avg, int n, int p, int iter, int n_iter)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    for (int g = blockIdx.x * 4 + w; g < n; g += nw) {
+        double r = lane < p ? rho_c[(size_t) g * p + lane] : 0.0;
+        const bool untouched = wave_max_d(r) == 0.0;
+        if (lane < p) {
+            if (untouched && have_avg) r = avg_di[lane];                  // correct_di_scores, nmf.py:157
+            const double x = xw[(size_t) g * p + lane];
+            rho_c[(size_t) g * p + lane] = r;
+            xadj[(size_t) g * p + lane] = x / (1.0 - r);                  // nmf.py:581
+            xw[(size_t) g * p + lane] = x / norm[lane];                   // nmf.py:587
+        }
+        if (lane == 0 && iter < n_iter) ran[(size_t) g * n_iter + iter] = flags[g] != 0;      // nmf.py:403
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const double *__restrict__ rho_raw, const int32_t *__restrict__ flags,
+                                                     const int64_t *__restrict__ rows, double *__restrict__ out_rho,
+                                                     int32_t *__restrict__ out_flags, int n_rows, int p)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * p) return;
+    const int k = t / p, i = t - k * p;
+    out_rho[t] = rho_raw[(size_t) rows[k] * p + i];
+    if (i == 0) out_flags[k] = flags[rows[k]];
+}
+
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -137,6 +237,10 @@ struct dn_handle_s {
     double  *d_svec = nullptr;
     int64_t *d_svoff = nullptr;
     float   *d_rowmax = nullptr;      // n x p row maxima of the raw coverage (k_row_max at upload)
+    // outer-update state (dn_outer_begin): clipped / corrected DI, x_weighted, x_adj, ran_baseline_selection, partial sums
+    double  *d_rhoc = nullptr, *d_xw = nullptr, *d_xadj = nullptr, *d_part = nullptr, *d_pvec = nullptr;
+    uint8_t *d_ran = nullptr;
+    int32_t  n_iter = 0;
     double  *d_est_sums = nullptr, *d_cov_sums = nullptr;
     int32_t *d_status = nullptr;
     double  *d_est = nullptr;
@@ -188,7 +292,8 @@ static void free_device(dn_handle h)
 {
     void *ptrs[] = {h->d_cov, h->d_goff, h->d_glen, h->d_order, h->d_counter, h->d_ds, h->d_ws, h->d_rho, h->d_flags,
                     h->d_trace, h->d_kfin, h->d_emode, h->d_svec, h->d_svoff, h->d_est_sums, h->d_cov_sums,
-                    h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col, h->d_rowmax};
+                    h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col, h->d_rowmax, h->d_rhoc, h->d_xw, h->d_xadj,
+                    h->d_part, h->d_pvec, h->d_ran};
     for (void *q : ptrs) if (q && q != (void *) h->cls[0].d_ws) (void) hipFree(q);
     for (auto &c : h->cls) {
         if (c.d_order) (void) hipFree(c.d_order);
@@ -201,6 +306,8 @@ static void free_device(dn_handle h)
     h->d_kfin = nullptr; h->d_emode = nullptr; h->d_svec = nullptr; h->d_svoff = nullptr; h->d_est_sums = nullptr;
     h->d_cov_sums = nullptr; h->d_status = nullptr; h->d_est = nullptr; h->d_tile_gene = nullptr; h->d_tile_col = nullptr;
     h->d_rowmax = nullptr;
+    h->d_rhoc = nullptr; h->d_xw = nullptr; h->d_xadj = nullptr; h->d_part = nullptr; h->d_pvec = nullptr; h->d_ran = nullptr;
+    h->n_iter = 0;
     h->have_estimate_state = false;
 }
 
@@ -568,7 +675,8 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
                           double *rho, int32_t *flags, int32_t *trace)
 {
     if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_baseline_iteration: nothing uploaded");
-    if (!scale || !prm || !rho || !flags) return fail(DN_E_INVALID, "dn_baseline_iteration: null argument");
+    if (!scale || !prm) return fail(DN_E_INVALID, "dn_baseline_iteration: null argument");
+    if ((rho == nullptr) != (flags == nullptr)) return fail(DN_E_INVALID, "dn_baseline_iteration: rho and flags are fetched together or not at all");
     if (prm->nmf_iter < 1) return fail(DN_E_INVALID, "nmf_iter must be >= 1");
     if (prm->bins < 1 || prm->bins > dn::MAX_BINS) return fail(DN_E_INVALID, "bins must be in [1, 64]");
     if (prm->min_high_coverage < 2) return fail(DN_E_INVALID, "min_high_coverage must be >= 2 (nmf.py:34)");
@@ -655,8 +763,10 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
         HIP_TRY(hipEventRecord(c == 0 ? h->ev1 : h->ev2b, st));
     }
     if (h->cls[1].n > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev2b, 0));     // results are copied on the main stream
-    HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
+    if (rho) {                          // null: the DI rows stay on the device (dn_outer_partials / dn_outer_apply / dn_fetch_outer)
+        HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
+    }
     h->host_trace.resize((size_t) h->n * dn::TRACE_LEN);
     HIP_TRY(hipMemcpyAsync(h->host_trace.data(), h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -673,6 +783,98 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
         h->last_span_ms = std::max(a, b);
     }
     h->have_estimate_state = prm->want_estimates != 0;
+    return DN_OK;
+}
+
+int dn_outer_begin(dn_handle h, const double *x_weighted, int32_t degnorm_iter)
+{
+    if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_outer_begin: nothing uploaded");
+    if (!x_weighted || degnorm_iter < 1) return fail(DN_E_INVALID, "dn_outer_begin: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t np = (size_t) h->n * h->p;
+    if (!h->d_rhoc) {
+        HIP_TRY(hipMalloc(&h->d_rhoc, sizeof(double) * np));
+        HIP_TRY(hipMalloc(&h->d_xw, sizeof(double) * np));
+        HIP_TRY(hipMalloc(&h->d_xadj, sizeof(double) * np));
+        HIP_TRY(hipMalloc(&h->d_part, sizeof(double) * (size_t) OUT_BLOCKS * OUT_STRIDE));
+        HIP_TRY(hipMalloc(&h->d_pvec, sizeof(double) * (3 * dn::P_MAX + 4 + 2 * dn::P_MAX)));
+    }
+    if (h->n_iter != degnorm_iter) {
+        if (h->d_ran) { (void) hipFree(h->d_ran); h->d_ran = nullptr; }
+        HIP_TRY(hipMalloc(&h->d_ran, (size_t) h->n * degnorm_iter));
+        h->n_iter = degnorm_iter;
+    }
+    HIP_TRY(hipMemsetAsync(h->d_ran, 0, (size_t) h->n * degnorm_iter, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_xw, x_weighted, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
+int dn_outer_partials(dn_handle h, double *partials)
+{
+    if (!h || !h->d_xw) return fail(DN_E_STATE, "dn_outer_partials: dn_outer_begin has not been called");
+    if (!partials) return fail(DN_E_INVALID, "dn_outer_partials: null output");
+    HIP_TRY(hipSetDevice(h->device));
+    const int blocks = (int) std::min<int64_t>(OUT_BLOCKS, (h->n + 3) / 4);
+    hipLaunchKernelGGL(k_outer_partials, dim3(blocks), dim3(256), 0, h->stream, h->d_rho, h->d_rhoc, h->d_xw, h->d_trace, h->d_part,
+                       (int) h->n, (int) h->p);
+    hipLaunchKernelGGL(k_outer_reduce, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_pvec, blocks, (int) h->p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(partials, h->d_pvec, sizeof(double) * (size_t) (3 * h->p + 3), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
+int dn_outer_apply(dn_handle h, const double *avg_di, const double *norm, int32_t iter)
+{
+    if (!h || !h->d_xw) return fail(DN_E_STATE, "dn_outer_apply: dn_outer_begin has not been called");
+    if (!norm || iter < 0) return fail(DN_E_INVALID, "dn_outer_apply: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    double *d_avg = h->d_pvec + (3 * dn::P_MAX + 4), *d_norm = d_avg + dn::P_MAX;
+    if (avg_di) HIP_TRY(hipMemcpyAsync(d_avg, avg_di, sizeof(double) * (size_t) h->p, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_norm, norm, sizeof(double) * (size_t) h->p, hipMemcpyHostToDevice, h->stream));
+    const int blocks = (int) std::min<int64_t>(OUT_BLOCKS, (h->n + 3) / 4);
+    hipLaunchKernelGGL(k_outer_apply, dim3(blocks), dim3(256), 0, h->stream, h->d_rhoc, h->d_xw, h->d_xadj, h->d_flags, h->d_ran, d_avg, d_norm,
+                       avg_di ? 1 : 0, (int) h->n, (int) h->p, (int) iter, (int) h->n_iter);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));           // the host buffers behind avg_di / norm may go away
+    return DN_OK;
+}
+
+int dn_fetch_outer(dn_handle h, double *rho, double *x_adj, double *x_weighted, uint8_t *ran)
+{
+    if (!h || !h->d_xw) return fail(DN_E_STATE, "dn_fetch_outer: dn_outer_begin has not been called");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t np = (size_t) h->n * h->p;
+    if (rho) HIP_TRY(hipMemcpyAsync(rho, h->d_rhoc, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    if (x_adj) HIP_TRY(hipMemcpyAsync(x_adj, h->d_xadj, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    if (x_weighted) HIP_TRY(hipMemcpyAsync(x_weighted, h->d_xw, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    if (ran) HIP_TRY(hipMemcpyAsync(ran, h->d_ran, (size_t) h->n * h->n_iter, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
+int dn_fetch_rows(dn_handle h, int64_t n_rows, const int64_t *rows, double *rho_raw, int32_t *flags)
+{
+    if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_fetch_rows: nothing uploaded");
+    if (n_rows <= 0 || !rows || !rho_raw || !flags) return fail(DN_E_INVALID, "dn_fetch_rows: bad argument");
+    for (int64_t k = 0; k < n_rows; k++) if (rows[k] < 0 || rows[k] >= h->n) return fail(DN_E_INVALID, "dn_fetch_rows: row out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    int64_t *d_rows = nullptr; double *d_out = nullptr; int32_t *d_fl = nullptr;
+    HIP_TRY(hipMalloc(&d_rows, sizeof(int64_t) * (size_t) n_rows));
+    hipError_t e = hipMalloc(&d_out, sizeof(double) * (size_t) n_rows * h->p);
+    if (e == hipSuccess) e = hipMalloc(&d_fl, sizeof(int32_t) * (size_t) n_rows);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows, sizeof(int64_t) * (size_t) n_rows, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        const int tot = (int) (n_rows * h->p);
+        hipLaunchKernelGGL(k_gather_rows, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->d_rho, h->d_flags, d_rows, d_out, d_fl, (int) n_rows, (int) h->p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rho_raw, d_out, sizeof(double) * (size_t) n_rows * h->p, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, d_fl, sizeof(int32_t) * (size_t) n_rows, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void) hipFree(d_rows); if (d_out) (void) hipFree(d_out); if (d_fl) (void) hipFree(d_fl);
+    if (e != hipSuccess) return fail(DN_E_HIP, std::string("dn_fetch_rows: ") + hipGetErrorString(e));
     return DN_OK;
 }
 

@@ -177,6 +177,9 @@ class ShardedNMFOA(object):
         self.scale_hist, self.rho_raw_hist, self.flags_hist, self.n_failed = [], [], [], []
         self.offsets_hist = []
         self.history_rows = None                          # optional: local gene rows whose raw DI / flags are kept per iteration
+        self.device_outer = True                          # False: the outer update in numpy on the host (same results)
+        self._device_outer = False
+        self._state_on_device = False
         self.downsample_offsets = None                    # optional (degnorm_iter x n_local) explicit starts
         self.n_local = 0
         self.n_total = 0
@@ -240,6 +243,12 @@ class ShardedNMFOA(object):
         self.ran_baseline_selection = np.zeros((self.n_local, self.degnorm_iter), dtype=bool)
         self._rng = np.random.RandomState(self.random_state)
         self.x_adj = None
+        # The O(n p) update between two sweeps runs on the device when it offers it (dn_outer_*): the DI matrix, the
+        # weighted and adjusted counts and the flags then stay in HBM and come back once, in fetch_state().
+        self._device_outer = self.device_outer and self.n_local > 0 and hasattr(self.dev, 'outer_begin')
+        if self._device_outer:
+            self.dev.outer_begin(self.x_weighted, max(1, self.degnorm_iter))
+        self._state_on_device = False
         self.kernel_ms, self.traces, self.class_ms, self.span_ms = [], [], [], []
         self.n_failed = []
         self.scale_hist, self.rho_raw_hist, self.flags_hist = [], [], []     # per outer iteration: inputs / raw device outputs
@@ -263,15 +272,14 @@ class ShardedNMFOA(object):
         p = self.p
         ds = self._offsets(i)
         self.offsets_hist.append(ds)
+        if self._device_outer:
+            return self._iterate_on_device(i, want_estimates, ds)
         if self.n_local > 0:
             rho, flags, trace = self.dev.baseline_iteration(
                 self.scale_factors, nmf_iter=self.nmf_iter, bins=self.bins, min_high_coverage=self.min_high_coverage,
                 downsample_rate=self.downsample_rate, skip_baseline_selection=self.skip_baseline_selection,
                 want_estimates=want_estimates, ds_start=ds)
-            self.kernel_ms.append(self.dev.last_kernel_ms())
-            if hasattr(self.dev, 'class_kernel_ms'):
-                self.class_ms.append((self.dev.class_kernel_ms(0), self.dev.class_kernel_ms(1)))
-                self.span_ms.append(self.dev.last_span_ms())
+            self._record_kernel_times()
         else:
             rho, flags, trace = np.zeros((0, p)), np.zeros(0, dtype=bool), np.zeros((0, _lib.TRACE_LEN), dtype=np.int32)
             self.kernel_ms.append(0.0)
@@ -293,7 +301,28 @@ class ShardedNMFOA(object):
         Wl = xw.sum(axis=0)
         n_fail = float(np.sum(trace[:, 6] != 0)) if trace is not None else 0.0
         n_noconv = float(np.sum(trace[:, 6] == -4)) if trace is not None else 0.0
-        tot = _allreduce(self.comm, np.concatenate([A, B, Wl, [float(untouched.sum()), n_fail, n_noconv]]))
+        avg_di, norm = self._reduce_and_update(i, np.concatenate([A, B, Wl, [float(untouched.sum()), n_fail, n_noconv]]))
+        if avg_di is not None:
+            rho[untouched, :] = avg_di
+        self.rho = rho
+        self.x_adj = xw / (1 - rho)                                   # nmf.py:581
+        self.x_weighted = xw / norm                                   # nmf.py:587
+        return self.scale_factors
+
+    def _record_kernel_times(self):
+        self.kernel_ms.append(self.dev.last_kernel_ms())
+        if hasattr(self.dev, 'class_kernel_ms'):
+            self.class_ms.append((self.dev.class_kernel_ms(0), self.dev.class_kernel_ms(1)))
+            self.span_ms.append(self.dev.last_span_ms())
+
+    def _reduce_and_update(self, i, partials):
+        """
+        The per-sample all-reduce of an outer iteration and what every rank derives from it identically
+        (nmf.py:148-158, :575-590): returns (avg_di or None, norm factors) and advances the scale factors.
+        partials = [A (p), B (p), W (p), #untouched, #failed genes, #unconverged genes] of this rank.
+        """
+        p = self.p
+        tot = _allreduce(self.comm, partials)
         A, B, Wt, n_untouched = tot[:p], tot[p:2 * p], tot[2 * p:3 * p], tot[3 * p]
         self.n_failed.append((int(tot[3 * p + 1]), int(tot[3 * p + 2])))
         if tot[3 * p + 1] > 0:                                        # the same warning on every rank
@@ -301,18 +330,41 @@ class ShardedNMFOA(object):
                             'raise), {2} of them an eigen-solve that did not converge; their DI scores were left at 0.'
                             .format(i + 1, int(tot[3 * p + 1]), int(tot[3 * p + 2])))
         S_pre = A + B                                                 # colsum of the first x_adj  (nmf.py:575)
+        avg_di = None
         if n_untouched > 0:
             avg_di = 1 - (Wt / S_pre)                                 # nmf.py:157
-            rho[untouched, :] = avg_di
             S_post = A + B / (1 - avg_di)                             # colsum of the second x_adj (nmf.py:581)
         else:
             S_post = S_pre
-        self.rho = rho
-        self.x_adj = xw / (1 - rho)                                   # nmf.py:581
         self.norm_factors = S_post / np.median(S_post)                # nmf.py:584
-        self.x_weighted = xw / self.norm_factors                      # nmf.py:587
         self.scale_factors = self.scale_factors * self.norm_factors   # nmf.py:590
+        return avg_di, self.norm_factors
+
+    def _iterate_on_device(self, i, want_estimates, ds):
+        """The same iteration with the DI matrix, x_weighted, x_adj and the flags resident in HBM."""
+        _, _, trace = self.dev.baseline_iteration(
+            self.scale_factors, nmf_iter=self.nmf_iter, bins=self.bins, min_high_coverage=self.min_high_coverage,
+            downsample_rate=self.downsample_rate, skip_baseline_selection=self.skip_baseline_selection,
+            want_estimates=want_estimates, ds_start=ds, fetch=False)
+        self._record_kernel_times()
+        self.traces.append(trace)
+        self.scale_hist.append(np.copy(self.scale_factors))
+        if self.history_rows is not None:
+            rho_rows, flag_rows = self.dev.fetch_rows(self.history_rows)
+            self.rho_raw_hist.append(rho_rows)
+            self.flags_hist.append(flag_rows)
+        avg_di, norm = self._reduce_and_update(i, self.dev.outer_partials())
+        self.dev.outer_apply(avg_di, norm, i)
+        self._state_on_device = True
+        self.rho = self.x_adj = None                                  # stale until fetch_state()
         return self.scale_factors
+
+    def fetch_state(self):
+        """Bring rho, x_adj, x_weighted and ran_baseline_selection back from the device (after the last iteration)."""
+        if self._state_on_device:
+            self.rho, self.x_adj, self.x_weighted, ran = self.dev.fetch_outer()
+            self.ran_baseline_selection = ran[:, :self.degnorm_iter]
+            self._state_on_device = False
 
     def run(self, want_estimates=True, flat=False):
         """Returns the estimates of the last iteration: a list of (p x L) arrays, or (flat buffer, lengths) if `flat`."""
@@ -330,6 +382,7 @@ class ShardedNMFOA(object):
                     est = (buf, np.asarray(self.dev.lengths, dtype=np.int64))
                 else:
                     est = self.dev.fetch_estimates()
+        self.fetch_state()
         return est
 
 

@@ -96,9 +96,29 @@ int  dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t 
  * (nmf.py:563-566 -> :142-146, :189-372; nmf_mpi.py:745-785), without the rho clip (host, nmf.py:398-399).
  * scale[p]: current scale factors.  ds_start (nullable unless downsample_rate > 1): per-gene
  * systematic-sample start offset in [0, rate) (nmf.py:422).
- * rho[n*p] (unclipped), flags[n] (ran_baseline_selection), trace[n*DN_TRACE_LEN] (nullable).         */
+ * rho[n*p] (unclipped), flags[n] (ran_baseline_selection) -- both NULL: kept on the device for the dn_outer_* calls;
+ * trace[n*DN_TRACE_LEN] (nullable).                                                                  */
 int  dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm, const int64_t *ds_start,
                            double *rho, int32_t *flags, int32_t *trace);
+
+/* The outer DegNorm update on the device ---------------------------------------------------------------
+ * Replaces: the O(n p) host arithmetic between two baseline-selection sweeps -- the DI clip (nmf.py:398-399),
+ * correct_di_scores (:148-158), x_adj (:575, :581), the normalisation of the weighted counts (:584-587) and the
+ * ran_baseline_selection column (:403); nmf_mpi.py:821-838 on rank 0.  With it dn_baseline_iteration may be called with
+ * rho = flags = NULL: the n x p DI matrix stays in HBM and the host sees 3p + 3 numbers per iteration.
+ *   dn_outer_begin     x_weighted (n x p, after the initial normalisation, nmf.py:534) -> device; degnorm_iter columns of flags
+ *   dn_outer_partials  after dn_baseline_iteration: partials[0:p] = sum over touched genes of x_w / (1 - rho),
+ *                      [p:2p] = sum over untouched genes (rho.max() == 0) of x_w, [2p:3p] = sum of x_w,
+ *                      [3p] = #untouched, [3p+1] = #genes with trace status != 0, [3p+2] = #genes with status -4
+ *                      (sums in a fixed order; the caller all-reduces them over the GPUs)
+ *   dn_outer_apply     rho[untouched] = avg_di (NULL: none untouched); x_adj = x_w / (1 - rho); x_w /= norm; flags -> column iter
+ *   dn_fetch_outer     final rho / x_adj / x_weighted (n x p each) and ran_baseline_selection (n x degnorm_iter bytes); any may be NULL
+ *   dn_fetch_rows      raw (unclipped) DI rows and flags of a few genes of the last dn_baseline_iteration (diagnostics)          */
+int  dn_outer_begin(dn_handle h, const double *x_weighted, int32_t degnorm_iter);
+int  dn_outer_partials(dn_handle h, double *partials);
+int  dn_outer_apply(dn_handle h, const double *avg_di, const double *norm, int32_t iter);
+int  dn_fetch_outer(dn_handle h, double *rho, double *x_adj, double *x_weighted, uint8_t *ran);
+int  dn_fetch_rows(dn_handle h, int64_t n_rows, const int64_t *rows, double *rho_raw, int32_t *flags);
 
 /* Estimated coverage matrices of the last dn_baseline_iteration run with want_estimates = 1 ----------
  * Replaces: the `estimate` output of baseline_selection (nmf.py:355-369), returned by run() (nmf.py:601).

@@ -107,3 +107,30 @@ def test_sharded_driver_over_rccl_world_size_1():
     np.testing.assert_allclose(res['x_adj'], G['single_x_adj'], rtol=1e-9)
     np.testing.assert_array_equal(res['flags'], G['single_flags'])
     assert res['rccl']
+
+
+def test_outer_update_on_the_device_equals_the_host_update():
+    """
+    The O(n p) arithmetic between two sweeps (DI clip, correct_di_scores, x_adj, normalisation: nmf.py:398-399, :148-158,
+    :575-590) on the device (dn_outer_*: the DI matrix never leaves HBM) against the same in numpy on the host, and both
+    against the reference's golden run on config-2 genes (3 outer iterations; untouched genes occur).
+    """
+    from degnorm_amd.nmf_mpi import ShardedNMFOA
+    G = golden('run_c2')
+    covs = [synth.synth_gene(int(G['seed']), int(g), int(G['p']), int(G['l_min']), int(G['l_max']))[0] for g in G['gene_ids']]
+    out = []
+    for on_device in (True, False):
+        eng = ShardedNMFOA(device=0, degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']))
+        eng.device_outer = on_device
+        eng.load(covs, G['reads'])
+        eng.run(want_estimates=False)
+        assert eng._device_outer == on_device
+        out.append(eng)
+        np.testing.assert_allclose(eng.rho, G['rho'], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(eng.x_adj, G['x_adj'], rtol=1e-9)
+        np.testing.assert_allclose(eng.x_weighted, G['x_weighted'], rtol=1e-9)
+        np.testing.assert_allclose(eng.scale_factors, G['scale_factors'], rtol=1e-9)
+        np.testing.assert_array_equal(eng.ran_baseline_selection, G['ran_baseline_selection'])
+    np.testing.assert_allclose(out[0].rho, out[1].rho, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(out[0].x_adj, out[1].x_adj, rtol=1e-12)
+    assert (out[0].rho.max(axis=1) == 0).sum() == 0 and (G['rho_hist'][0].max(axis=1) == 0).any()     # untouched genes were corrected
