@@ -48,6 +48,11 @@
 #ifndef DN_MIN_WAVES
 #define DN_MIN_WAVES 1
 #endif
+#ifndef DN_RAW_UNITS
+#define DN_RAW_UNITS 0           // 1: narrow cohorts keep x + lambda in raw count units (one fp64 instruction less per element and
+                                 // pass: 156 instead of 164 instructions per column at p = 10) -- parity-green, but measured 1.6 % SLOWER
+                                 // on config 2 (344.3 vs 339.0 ms per sweep), so it stays off
+#endif
 
 namespace dn {
 
@@ -148,6 +153,7 @@ struct Smem {
     double xw[W][NX];                        // per-wave totals (cross-wave combine)
     double tot[NX];                          // block totals (broadcast)
     double dsel[NX];                         // 1.0 at the packed indices of the Gram diagonal, else 0.0
+    double gsc[NX];                          // 1 / (s_i s_j) at packed index (i, j): Gram matrix of raw counts -> of scaled counts
     double stage[P >= DN_MG_MIN_P ? W * 16 * MG_STR : 2];      // per wave: 16 updated columns in the MFMA operand layout
     double eigv[P >= DN_MG_MIN_P ? W * 2 * 64 : 2];            // per wave: current eigenvector u and a work vector
     double ss[MAX_BINS];                     // per-bin mean squared residual
@@ -191,7 +197,7 @@ __device__ __forceinline__ double uniform(double v)
 // One round of the per-wave reduction: entries [OFF, OFF + CNT) of g, CNT <= 64, totals into dst[OFF + entry].
 template <int N, int OFF, typename VT>
 __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, int lane, double diag_shift, const double *dsel,
-                                                 bool shift_here)
+                                                 bool shift_here, const double *gsc = nullptr)
 {
     constexpr int CNT = (N - OFF) < 64 ? (N - OFF) : 64;
     VT part[CNT];
@@ -200,13 +206,15 @@ __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, 
     double s = wave_reduce_scatter<CNT, VT>(part, lane);
     const int e = reduce_scatter_entry(lane);
     if (e < CNT) {
+        if (gsc) s *= gsc[OFF + e];
         if (shift_here) s = fma(-diag_shift, dsel[OFF + e], s);
         dst[OFF + e] = s;
     }
-    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT>(g, dst, lane, diag_shift, dsel, shift_here);
+    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT>(g, dst, lane, diag_shift, dsel, shift_here, gsc);
 }
 
-template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0>    // OFF: the totals go to tot[OFF .. OFF + N)
+// SCALE: the values are Gram entries of the RAW counts; the totals are multiplied by gsc (1 / (s_i s_j)) on the way out
+template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0, bool SCALE = false>    // OFF: the totals go to tot[OFF .. OFF + N)
 __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm, double diag_shift = 0.0)
 {
     static_assert(OFF + N <= Smem<P, NT>::NX - 1, "xw too small");
@@ -214,13 +222,14 @@ __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm,
     constexpr int W = NT / 64;
     const int lane = lane_id(), w = wave_id();
     double *dst = ((W > 1) ? sm.xw[w] : sm.tot) + OFF;
-    wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1);     // ceil(N / 64) rounds
+    wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1, (SCALE && W == 1) ? sm.gsc + OFF : nullptr);     // ceil(N / 64) rounds
     if constexpr (W > 1) {
         __syncthreads();
         for (int e = OFF + threadIdx.x; e < OFF + N; e += NT) {         // one trip unless N > NT
             double t = sm.xw[0][e];
 #pragma unroll
             for (int ww = 1; ww < W; ww++) t += sm.xw[ww][e];
+            if constexpr (SCALE) t *= sm.gsc[e];
             if constexpr (SHIFT) t = fma(-diag_shift, sm.dsel[e], t);                // G - mu I for the eigen-solver
             sm.tot[e] = t;
         }
@@ -775,6 +784,7 @@ struct GeneState {
     double rho_fb[P];    // DI of max(K_start E_start, F_start)                   nmf.py:345-346, :352-353
     double sig0;         // sigma of the first call
     double inv[P];       // 1 / scale factors
+    double scl[P];       // scale factors
     double u[P];         // outputs of the last nmf() call: top left singular vector,
     double theta;        //   sigma^2,
     double sums[2 * P + 1];   // { sum_j s_j, clamped row sums (P), row sums of Fb (P) }
@@ -823,6 +833,23 @@ __device__ __forceinline__ void col_update(const double (&f)[P], double (&a)[P],
         const double res = fma(u[i], s, -f[i]);                        // est - x                       nmf.py:94
         a[i] = fmax(fma(-c, res, a[i]), f[i]);                         // x + max(lambda - c res, 0)    nmf.py:95-97
     }
+}
+
+// The same step with the state kept in RAW count units, A = a * s_i (a = x / s + lambda is the reference's scaled state):
+//     s = u . a = sum_i (u_i / s_i) A_i = w . A,        A' = a' s_i = max(A - c s_i (u_i s) + c x, x) = max(fma(-v_i, s, fma(c, x, A)), x)
+// with w_i = u_i / s_i and v_i = c u_i s_i per solve (wave-uniform).  The raw counts enter as they are (one conversion, no
+// multiplication by 1 / s_i): 4 fp64 instructions per element instead of 5, and the cold state is x itself.  The Gram
+// matrix is accumulated in raw units too and scaled once per inner iteration on the way out of the block reduction.
+template <int P>
+__device__ __forceinline__ void col_update_raw(const double (&x)[P], double (&a)[P], const double (&w)[P], const double (&v)[P], double c)
+{
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i + 1 < P; i += 2) { s0 = fma(w[i], a[i], s0); s1 = fma(w[i + 1], a[i + 1], s1); }
+    if (P & 1) s0 = fma(w[P - 1], a[P - 1], s0);
+    const double s = s0 + s1;                                          // E_j * sigma = u . (x / s + lambda)_j
+#pragma unroll
+    for (int i = 0; i < P; i++) a[i] = fmax(fma(-v[i], s, fma(c, x[i], a[i])), x[i]);   // nmf.py:94-97 times s_i
 }
 
 // Wide cohorts: u and 1/s come from LDS (broadcast loads) and F = x / s is formed element by element, so that next to
@@ -914,6 +941,15 @@ __device__ __forceinline__ void load_f(gF_cptr Fb, int k, const double (&inv)[P]
     load_x<P>(Fb, k, x);
 #pragma unroll
     for (int i = 0; i < P; i++) f[i] = (double) x[i] * inv[i];
+}
+
+template <int P>
+__device__ __forceinline__ void load_xd(gF_cptr Fb, int k, double (&xd)[P])
+{
+    float x[P];
+    load_x<P>(Fb, k, x);
+#pragma unroll
+    for (int i = 0; i < P; i++) xd[i] = (double) x[i];
 }
 
 // Spill-tier layout: blocks of 64 columns, inside a block the p rows of 64 doubles back to back.  A wave (64 consecutive
@@ -1252,6 +1288,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     constexpr int CH = (NG + SW - 1) / SW;
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
     const int tid = threadIdx.x;
+    constexpr bool RAW = DN_RAW_UNITS && P < DN_MG_MIN_P;  // state and Gram partials in raw count units (col_update_raw)
     constexpr int RT = DN_REG_TIER ? rt_cols<P>() : 0;     // columns per lane held in AGPRs (register tier)
     constexpr int NR = RT * NT;                            // the gene's first NR columns
     const int nLe = (n < NR + nL) ? n : NR + nL;           // end of the LDS tier (absolute column); LDS slot of column k: k - NR
@@ -1271,10 +1308,10 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #pragma clang loop unroll(disable)
     for (int k = tid; k < n; k += NT) {
         double f[P];
-        load_f<P>(Fb, k, inv, f);
+        if constexpr (RAW) load_xd<P>(Fb, k, f); else load_f<P>(Fb, k, inv, f);
         gram_add_range<P, 0, CH>(G, f);
     }
-    block_sum_lds<CH, P, NT, gram_t>(G, sm);
+    block_sum_lds<CH, P, NT, gram_t, false, 0, RAW>(G, sm);
     static_for<1, SW>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int NQ = (NG - Q * CH) < CH ? (NG - Q * CH) : CH;
@@ -1284,10 +1321,10 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #pragma clang loop unroll(disable)
         for (int k = tid; k < n; k += NT) {
             double f[P];
-            load_f<P>(Fb, k, inv, f);
+            if constexpr (RAW) load_xd<P>(Fb, k, f); else load_f<P>(Fb, k, inv, f);
             gram_add_range<P, Q * CH, NQ>(Gq, f);
         }
-        block_sum_lds<NQ, P, NT, gram_t, false, Q * CH>(Gq, g_sm);
+        block_sum_lds<NQ, P, NT, gram_t, false, Q * CH, RAW>(Gq, g_sm);
     });
     {
         double tr = 0.0;
@@ -1303,26 +1340,30 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         solver.cold(tr, u);
     }
     { const int r = solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, T == 0, maxs); steps += r; noconv = noconv || r > maxs; }
+    const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
+    double uw[P], uv[P];                                              // raw units: w_i = u_i / s_i, v_i = c u_i s_i
 #pragma unroll
-    for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
+    for (int i = 0; i < P; i++) {
+        u[i] = uniform(u[i]);                                         // keep u in scalar registers: two-VGPR-source FMAs
+        if constexpr (RAW) { uw[i] = uniform(u[i] * inv[i]); uv[i] = uniform(c * u[i] * g_gs.scl[i]); }
+    }
 
     static_for<0, RT>([&](auto rc) {                             // lmbda = zeros (nmf.py:90): state a = x
         constexpr int R = decltype(rc)::value;
         const int k = tid + R * NT;
         if (k < n) {
             double f[P];
-            load_f<P>(Fb, k, inv, f);
+            if constexpr (RAW) load_xd<P>(Fb, k, f); else load_f<P>(Fb, k, inv, f);
             rt_write<P, R>(f);
         }
     });
     for (int k = NR + tid; k < nLe; k += NT) {
         double f[P], a[PS];
-        load_f<P>(Fb, k, inv, f);
+        if constexpr (RAW) load_xd<P>(Fb, k, f); else load_f<P>(Fb, k, inv, f);
 #pragma unroll
         for (int i = 0; i < PS; i++) a[i] = i < P ? f[i] : 0.0;
         lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
     }
-    const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
 #ifdef DN_STAMP
     stamp[3] += __builtin_amdgcn_s_memtime() - t_cold0;
 #endif
@@ -1348,6 +1389,8 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         // register tier: unrolled over the lane's RT columns, the next column's counts requested before this one's arithmetic
         auto reg_tier = [&]() {
             if constexpr (RT > 0) {
+                // the next column's counts are requested before this column's arithmetic starts (two columns ahead with two
+                // buffers measured no faster: 341.9 vs 339.0 ms per sweep)
                 float xq[P];
                 if (tid < n) load_x<P>(Fb, tid, xq);
                 static_for<0, RT>([&](auto rc) {
@@ -1356,10 +1399,10 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                     if (k < n) {
                         double f[P], a[P];
 #pragma unroll
-                        for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
+                        for (int i = 0; i < P; i++) f[i] = RAW ? (double) xq[i] : (double) xq[i] * inv[i];
                         if constexpr (R + 1 < RT) load_x<P>(Fb, k + NT < n ? k + NT : k, xq);
                         rt_read<P, R>(a);
-                        col_update<P>(f, a, u, c);
+                        if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
                         gram_add_range<P, 0, CH>(G, a);
                         rt_write<P, R>(a);
                     }
@@ -1378,12 +1421,12 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                 double f[P], a[PS];
                 lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
 #pragma unroll
-                for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
+                for (int i = 0; i < P; i++) f[i] = RAW ? (double) xq[i] : (double) xq[i] * inv[i];
                 load_x<P>(Fb, j + 1 < cnt ? k + step : k, xq);      // unconditional (clamped): no branch around the loads
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
-                col_update<P>(f, aa, u, c);
+                if constexpr (RAW) col_update_raw<P>(f, aa, uw, uv, c); else col_update<P>(f, aa, u, c);
                 gram_add_range<P, 0, CH>(G, aa);
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
@@ -1410,7 +1453,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             for (int j = 0; j < cnt; j++, k += step) {
                 double f[P], a[P];
 #pragma unroll
-                for (int i = 0; i < P; i++) { f[i] = (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
+                for (int i = 0; i < P; i++) { f[i] = RAW ? (double) xn[i] : (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
                 if (j + 1 < cnt) {
                     load_x<P>(Fb, k + step, xn);
                     if (t > 0) {
@@ -1418,7 +1461,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                         for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k + step) + i * 64);
                     }
                 }
-                col_update<P>(f, a, u, c);
+                if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
                 gram_add_range<P, 0, CH>(G, a);
 #pragma unroll
                 for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], spill_ptr<P>(Lg, k) + i * 64);
@@ -1427,7 +1470,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         if (dir > 0) { reg_tier(); lds_tier(); spill_tier(); }
         else { spill_tier(); lds_tier(); reg_tier(); }
         DN_T1(0); }
-        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
+        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED, 0, RAW>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
         // later sweeps (p >= 16): the remaining Gram entries from the updated state, read-only
         static_for<1, SW>([&](auto qc) {
             constexpr int Q = decltype(qc)::value;
@@ -1451,13 +1494,16 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                 for (int i = 0; i < P; i++) aa[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
                 gram_add_range<P, Q * CH, NQ>(Gq, aa);
             }
-            block_sum_lds<NQ, P, NT, gram_t, Solver<P>::SHIFTED, Q * CH>(Gq, g_sm, solver.shift());
+            block_sum_lds<NQ, P, NT, gram_t, Solver<P>::SHIFTED, Q * CH, RAW>(Gq, g_sm, solver.shift());
         });
         { DN_T0();
         const int r = solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, t == T - 1, maxs);   // sigma^2 is only read after the last solve
         steps += r; noconv = noconv || r > maxs;
 #pragma unroll
-        for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
+        for (int i = 0; i < P; i++) {
+            u[i] = uniform(u[i]);
+            if constexpr (RAW) { uw[i] = uniform(u[i] * inv[i]); uv[i] = uniform(c * u[i] * g_gs.scl[i]); }
+        }
         DN_T1(2); }
     }
     }   // narrow cohorts
@@ -1469,9 +1515,11 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     double acc[2 * P + 1];
 #pragma unroll
     for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
-    auto fin = [&](int k, const double (&l)[P]) {
-        double f[P], s, r;
+    auto fin = [&](int k, const double (&l0)[P]) {
+        double f[P], l[P], s, r;
         load_f<P>(Fb, k, inv, f);
+#pragma unroll
+        for (int i = 0; i < P; i++) l[i] = RAW ? l0[i] * inv[i] : l0[i];          // back to the reference's scaled units
         col_final<P>(f, l, u, first, acc, s, r);
         rs[k] = r;
         if (first) sv[k] = s;
@@ -1565,7 +1613,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
     double *rs = sv + S;                                              // residual profile               [S]
     double *rtsave = rs + 2 * (size_t) S;                             // caller's AGPRs during an nmf() call  [RT * P][NT]
     DN_RT_CLAIM();
-    if (tid < P) gs.inv[tid] = A.inv_scale[tid];
+    if (tid < P) { gs.inv[tid] = A.inv_scale[tid]; gs.scl[tid] = A.scale[tid]; }
     if (tid == 0) gs.max_steps = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
     for (int t = tid; t < Smem<P, NT>::NX; t += NT) {                  // constants of the eigen-solver (top_eig_mfma)
         bool diag = false;
@@ -1573,6 +1621,12 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
         for (int i = 0; i < P; i++) diag = diag || (t == i * (i + 1) / 2 + i);
         sm.dsel[t] = diag ? 1.0 : 0.0;
         if (t == Smem<P, NT>::ZSLOT) sm.tot[t] = 0.0;
+        double sc = 1.0;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) if (t == i * (i + 1) / 2 + j) sc = A.inv_scale[i] * A.inv_scale[j];
+        sm.gsc[t] = sc;
     }
 
     for (;;) {

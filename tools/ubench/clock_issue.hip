@@ -10,8 +10,8 @@
 #include <vector>
 #include <algorithm>
 
-template <int MODE>
-__global__ void k(double *sink, long long *stamps, int iters)
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void k(double *sink, long long *stamps, int iters)
 {
     double a[16], b[16];
     for (int i = 0; i < 16; i++) { a[i] = threadIdx.x * 1e-3 + i; b[i] = 1.0 + 1e-9 * (threadIdx.x + i); }
@@ -29,6 +29,59 @@ __global__ void k(double *sink, long long *stamps, int iters)
         } else if (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < 16; i++) a[i] = fma(b[i], b[(i + 5) & 15], a[i]);
+        } else if (MODE == 4 || MODE == 5) {
+            // the scaled column with its state in AGPRs: 20 v_accvgpr_read before, 20 v_accvgpr_write after (MODE 5: reads only)
+            double f[10], s0 = 0.0, s1 = 0.0;
+            int lo[10], hi[10];
+#define RD(I) asm volatile("v_accvgpr_read_b32 %0, a" #I : "=v"(lo[I / 2])); asm volatile("v_accvgpr_read_b32 %0, a" #I "+1" : "=v"(hi[I / 2]));
+            asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1" : "=v"(lo[0]), "=v"(hi[0]));
+            asm volatile("v_accvgpr_read_b32 %0, a2\n\tv_accvgpr_read_b32 %1, a3" : "=v"(lo[1]), "=v"(hi[1]));
+            asm volatile("v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5" : "=v"(lo[2]), "=v"(hi[2]));
+            asm volatile("v_accvgpr_read_b32 %0, a6\n\tv_accvgpr_read_b32 %1, a7" : "=v"(lo[3]), "=v"(hi[3]));
+            asm volatile("v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9" : "=v"(lo[4]), "=v"(hi[4]));
+            asm volatile("v_accvgpr_read_b32 %0, a10\n\tv_accvgpr_read_b32 %1, a11" : "=v"(lo[5]), "=v"(hi[5]));
+            asm volatile("v_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a13" : "=v"(lo[6]), "=v"(hi[6]));
+            asm volatile("v_accvgpr_read_b32 %0, a14\n\tv_accvgpr_read_b32 %1, a15" : "=v"(lo[7]), "=v"(hi[7]));
+            asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17" : "=v"(lo[8]), "=v"(hi[8]));
+            asm volatile("v_accvgpr_read_b32 %0, a18\n\tv_accvgpr_read_b32 %1, a19" : "=v"(lo[9]), "=v"(hi[9]));
+#pragma unroll
+            for (int i = 0; i < 10; i++) a[i] = __hiloint2double(hi[i], lo[i]);
+#pragma unroll
+            for (int i = 0; i < 10; i++) f[i] = (double) x[i] * (1.0 + 0.01 * i);
+#pragma unroll
+            for (int i = 0; i < 10; i += 2) { s0 = fma(0.3 + 0.01 * i, a[i], s0); s1 = fma(0.31 + 0.01 * i, a[i + 1], s1); }
+            const double s = s0 + s1;
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                const double res = fma(0.3 + 0.01 * i, s, -f[i]);
+                a[i] = fmax(fma(-0.1, res, a[i]), f[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 10; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = fma(a[i], a[j], G[i * (i + 1) / 2 + j]);
+            if (MODE == 4) {
+#define WR(A0, A1, I) asm volatile("v_accvgpr_write_b32 a" #A0 ", %0\n\tv_accvgpr_write_b32 a" #A1 ", %1" : : "v"(__double2loint(a[I])), "v"(__double2hiint(a[I])));
+                WR(0, 1, 0) WR(2, 3, 1) WR(4, 5, 2) WR(6, 7, 3) WR(8, 9, 4) WR(10, 11, 5) WR(12, 13, 6) WR(14, 15, 7) WR(16, 17, 8) WR(18, 19, 9)
+            }
+#pragma unroll
+            for (int i = 0; i < 10; i++) x[i] += 1.0f;
+        } else if (MODE == 3) {
+            // the same column in raw count units (col_update_raw): 4 instead of 5 fp64 instructions per element
+            double f[10], s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) f[i] = (double) x[i];
+#pragma unroll
+            for (int i = 0; i < 10; i += 2) { s0 = fma(0.3 + 0.01 * i, a[i], s0); s1 = fma(0.31 + 0.01 * i, a[i + 1], s1); }
+            const double s = s0 + s1;
+#pragma unroll
+            for (int i = 0; i < 10; i++) a[i] = fmax(fma(-(0.03 + 0.001 * i), s, fma(0.1, f[i], a[i])), f[i]);
+#pragma unroll
+            for (int i = 0; i < 10; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) G[i * (i + 1) / 2 + j] = fma(a[i], a[j], G[i * (i + 1) / 2 + j]);
+#pragma unroll
+            for (int i = 0; i < 10; i++) x[i] += 1.0f;
         } else {
             // one column of the pass, registers only
             double f[10], s0 = 0.0, s1 = 0.0;
@@ -56,6 +109,7 @@ __global__ void k(double *sink, long long *stamps, int iters)
     for (int i = 0; i < 16; i++) sum += a[i] + b[i];
     for (int i = 0; i < 55; i++) sum += G[i];
     for (int i = 0; i < 10; i++) sum += x[i];
+    if (MODE >= 4) asm volatile("" ::: "a19");
     if (sum == 12345.678) sink[0] = sum;
     if ((threadIdx.x & 63) == 0) {
         const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -68,19 +122,24 @@ int main()
 {
     double *d; hipMalloc(&d, 64);
     long long *st; hipMalloc(&st, sizeof(long long) * 2 * 256 * 16);
-    const char *names[] = {"v_fma_f64, 1 VGPR source", "v_fma_f64, 3 VGPR sources", "column of the p=10 pass (125 instr)"};
-    const double per_iter[] = {16.0, 16.0, 125.0};
-    for (int mode = 0; mode < 3; mode++)
+    const char *names[] = {"v_fma_f64, 1 VGPR source", "v_fma_f64, 3 VGPR sources", "column of the p=10 pass (125 instr)", "column, raw units (115 instr)", "column + 20 accvgpr reads + 20 writes (165)", "column + 20 accvgpr reads (145)"};
+    const double per_iter[] = {16.0, 16.0, 125.0, 115.0, 165.0, 145.0};
+    for (int mode = 0; mode < 6; mode++)
         for (int wps = 1; wps <= 4; wps *= 2) {
+            if (mode >= 2 && wps > 2) continue;            // the column body needs > 128 registers
             const int threads = 256 * wps;
-            const int iters = mode == 2 ? 40000 : 300000;          // a few ms per launch; three launches, the last is reported
+            const int iters = mode >= 2 ? 40000 : 300000;          // a few ms per launch; three launches, the last is reported
             float ms = 0;
             for (int rep = 0; rep < 3; rep++) {
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 hipEventRecord(e0, 0);
-                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, d, st, iters);
-                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, d, st, iters);
-                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(threads), 0, 0, d, st, iters);
+#define DN_LAUNCH(M, T) hipLaunchKernelGGL((k<M, T>), dim3(256), dim3(T), 0, 0, d, st, iters)
+                if (mode == 0) { if (wps == 1) DN_LAUNCH(0, 256); else if (wps == 2) DN_LAUNCH(0, 512); else DN_LAUNCH(0, 1024); }
+                if (mode == 1) { if (wps == 1) DN_LAUNCH(1, 256); else if (wps == 2) DN_LAUNCH(1, 512); else DN_LAUNCH(1, 1024); }
+                if (mode == 2) { if (wps == 1) DN_LAUNCH(2, 256); else DN_LAUNCH(2, 512); }
+                if (mode == 3) { if (wps == 1) DN_LAUNCH(3, 256); else DN_LAUNCH(3, 512); }
+                if (mode == 4) { if (wps == 1) DN_LAUNCH(4, 256); else DN_LAUNCH(4, 512); }
+                if (mode == 5) { if (wps == 1) DN_LAUNCH(5, 256); else DN_LAUNCH(5, 512); }
                 hipEventRecord(e1, 0);
                 hipDeviceSynchronize();
                 hipEventElapsedTime(&ms, e0, e1);
