@@ -39,10 +39,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz (AMD MI355X spec)
-# tools/ubench/clock_issue.hip on the box (profiles/round2/ubench_clock_issue.txt): one wave alone on a SIMD issues one
-# fp64 FMA per 5.75 cycles (VGPR sources; 6.75 with an SGPR-pair source) at an in-kernel clock of 2.39 GHz, against the
-# 4 cycles of the peak above; four waves per SIMD reach 4.4.  The kernel runs one wave per SIMD (LDS holds one gene).
-FP64_ISSUE_CYCLES_1WAVE = 5.75
+# tools/ubench/clock_issue.hip on the box (profiles/round2/ubench_clock_issue.txt), in-kernel clock 2.37-2.39 GHz: ONE wave
+# alone on a SIMD issues the instruction mix of a column of the pass (10 cvt + 10 mul + 30 fma + 10 max + 55 Gram fma,
+# registers only) at 4.22 cycles per instruction against the 4 of the peak above (two waves per SIMD: 3.95); a stream of
+# nothing but dependent-free fp64 FMAs issues slower (5.75, 4.4 with four waves).  The kernel runs one wave per SIMD.
+FP64_ISSUE_CYCLES_1WAVE = 4.22
 ROUND = 'round2'
 
 
@@ -320,37 +321,43 @@ def main():
             flop_a, instr_a = work(np.ones(len(lengths), dtype=bool))
             alg_d = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter, mask) for tr in all_traces]))
             alg_all = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in all_traces]))
-            tflops = flop_d / (avg_ms * 1e-3) / 1e12
+            tflops = flop_a / (avg_ms * 1e-3) / 1e12
             simd_cycles = lambda ms: ms * 1e-3 * 2.4e9 * 256 * 4
             issue_peak = FP64_VECTOR_PEAK_TFLOPS * 4.0 / FP64_ISSUE_CYCLES_1WAVE
             traffic, tinfo = pmc_traffic(args.config, name_d, int(mask.sum())) if (world == 1 and n_genes == cfg['n_genes']) else (None, {'refused': 'not the profiled shard'})
+            traffic_o, tinfo_o = pmc_traffic(args.config, eng.dev.class_kernel_name(oth), int(cls_mask[oth].sum())) if traffic is not None else (None, None)
+            traffic_pair = (traffic + traffic_o) if (traffic is not None and traffic_o is not None) else None
             out['roofline'] = {
                 'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tflops / FP64_VECTOR_PEAK_TFLOPS,
-                'issue_ceiling': {'peak': issue_peak, 'frac': tflops / issue_peak,
-                                  'what': 'one wave per SIMD issues one fp64 FMA per {0} cycles, not 4 (tools/ubench/clock_issue.hip, '
-                                          'in-kernel clock 2.39 GHz; profiles/{1}/ubench_clock_issue.txt)'.format(FP64_ISSUE_CYCLES_1WAVE, ROUND)},
-                'valu_issue_slots': {'wave_instructions': instr_d, 'slots_frac': instr_d * 4.0 / simd_cycles(avg_ms),
-                                     'what': 'fp64 wave-instructions of the passes x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs)'},
-                'flop_per_column_iteration': p * p + 9.0 * p,
-                'traffic': traffic, 'traffic_info': tinfo,
-                'traffic_rate_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
-                'traffic_frac_of_hbm_peak': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                'hbm_algorithmic': {'bytes_per_launch': alg_d, 'rate_gbps': alg_d / (avg_ms * 1e-3) / 1e9, 'hbm_peak_gbps': HBM_PEAK_GBPS,
-                                    'ratio_to_hbm_peak': alg_d / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                    'what': 'SURVEY 8(d) algorithmic bytes (fp32 x and lambda re-streamed every inner iteration) / kernel time; '
-                                            'NOT a roofline fraction: the kernel keeps x + lambda on chip, so these bytes are mostly never moved'},
+                'what': 'fp64 vector work of ALL genes (both class kernels) / average launch duration of the dominant kernel: the '
+                        'dominant kernel is launched right behind the other one on a second stream and is the last to end, so its '
+                        'launch spans the whole sweep and the other kernel runs INSIDE that window',
                 'kernel': name_d, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
                 'genes_in_kernel': int(mask.sum()), 'split_length': split,
-                'second_kernel': {'kernel': eng.dev.class_kernel_name(oth), 'genes': int(cls_mask[oth].sum()),
-                                  'avg_launch_ms': cls_ms[oth],
-                                  'algorithmic_bytes_per_launch': alg_all - alg_d,
-                                  'note': 'the other gene class, own stream, runs beside the dominant kernel'},
-                'iteration': {'span_ms': span_ms, 'fp64_tflops': flop_a / (span_ms * 1e-3) / 1e12,
-                              'frac_of_peak': flop_a / (span_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                              'frac_of_issue_ceiling': flop_a / (span_ms * 1e-3) / 1e12 / issue_peak,
-                              'valu_issue_slots_frac': instr_a * 4.0 / simd_cycles(span_ms),
-                              'what': 'both kernels of an outer iteration: all genes\' fp64 work / time from the first launch to the last end'},
+                'concurrent_kernel': {'kernel': eng.dev.class_kernel_name(oth), 'genes': int(cls_mask[oth].sum()),
+                                      'avg_launch_ms': cls_ms[oth], 'sweep_span_ms': span_ms,
+                                      'note': 'the other gene class, own stream, launched first'},
+                'dominant_kernel_own_work': {'fp64_tflops': flop_d / (avg_ms * 1e-3) / 1e12,
+                                             'frac': flop_d / (avg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                             'note': 'only the dominant kernel\'s genes over its launch duration (it has the chip to itself '
+                                                     'for only part of that time)'},
+                'issue_ceiling': {'peak': issue_peak, 'frac': tflops / issue_peak,
+                                  'what': 'one wave per SIMD issues the column\'s instruction mix at {0} cycles per instruction, not 4 '
+                                          '(tools/ubench/clock_issue.hip, in-kernel clock 2.37-2.39 GHz; profiles/{1}/ubench_clock_issue.txt)'
+                                          .format(FP64_ISSUE_CYCLES_1WAVE, ROUND)},
+                'valu_issue_slots': {'wave_instructions': instr_a, 'slots_frac': instr_a * 4.0 / simd_cycles(avg_ms),
+                                     'what': 'fp64 wave-instructions of the passes x 4 cycles / (sweep time x 2.4 GHz x 1024 SIMDs)'},
+                'flop_per_column_iteration': p * p + 9.0 * p,
+                'traffic': traffic_pair, 'traffic_info': tinfo,
+                'traffic_per_kernel': {name_d: traffic, eng.dev.class_kernel_name(oth): traffic_o},
+                'traffic_rate_gbps': (traffic_pair / (avg_ms * 1e-3) / 1e9) if traffic_pair else None,
+                'traffic_frac_of_hbm_peak': (traffic_pair / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_pair else None,
+                'hbm_algorithmic': {'bytes_per_sweep': alg_all, 'rate_gbps': alg_all / (avg_ms * 1e-3) / 1e9, 'hbm_peak_gbps': HBM_PEAK_GBPS,
+                                    'ratio_to_hbm_peak': alg_all / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    'what': 'SURVEY 8(d) algorithmic bytes (fp32 x and lambda re-streamed every inner iteration) / sweep time; '
+                                            'NOT a roofline fraction: the kernels keep x + lambda on chip (registers + LDS), so these bytes are '
+                                            'mostly never moved'},
                 'note': 'rank-0 shard; HIP events on the library streams around each launch'}
         else:
             # config 4: after the row-maxima shortcut an outer iteration reads only the sampled columns; the kernel that

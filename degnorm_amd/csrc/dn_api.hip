@@ -667,7 +667,7 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipEventElapsedTime(&h->last_init_ms, h->ev_i0, h->ev_i1));
     if (h->ks->p >= 2 && h->ks->p <= 16) snprintf(h->init_name, sizeof(h->init_name), "k_ratio_svd<%d,%d>", h->ks->p, h->ks->nt);
-    else snprintf(h->init_name, sizeof(h->init_name), (h->p >= 17 && !(getenv("DN_INIT_POWER") && getenv("DN_INIT_POWER")[0] == '1')) ? "k_ratio_svd_mg" : "k_ratio_svd_gen");
+    else snprintf(h->init_name, sizeof(h->init_name), (h->p >= 17 && !(getenv("DN_INIT_POWER") && getenv("DN_INIT_POWER")[0] == '1')) ? "gen::k_ratio_svd_mg" : "gen::k_ratio_svd_gen");
     return DN_OK;
 }
 

@@ -399,7 +399,7 @@ def test_full_size_properties_config4(device, oracle, monkeypatch):
     assert np.array_equal(rho1, rho2) and np.array_equal(fl1, fl2) and np.array_equal(tr1[:, :40], tr2[:, :40])
     assert np.all(tr1[:, 6] == 0) and np.isfinite(rho1).all()
     assert np.all(tr1[:, 0] <= (lengths - ds + rate - 1) // rate)
-    assert (tr1[:, 1] > 1).sum() > n // 10 and device.class_kernel_name(0) == 'k_baseline_rows'
+    assert (tr1[:, 1] > 1).sum() > n // 10 and device.class_kernel_name(0) == 'gen_rows::k_baseline_gen'
 
     offs = np.concatenate([[0], np.cumsum(lengths * p)])
     head = np.arange(48)
@@ -424,7 +424,7 @@ def test_full_size_properties_config4(device, oracle, monkeypatch):
             dev2.hint_downsample(rate)
             dev2.upload_packed(sub_packed, lengths[sub], p)
             rho_s, fl_s, tr_s = dev2.baseline_iteration(scale, ds_start=ds[sub], **kw)
-            assert dev2.class_kernel_name(0) == ('k_baseline_gen' if force else 'k_baseline_rows')
+            assert dev2.class_kernel_name(0) == ('gen::k_baseline_gen' if force else 'gen_rows::k_baseline_gen')
             assert np.array_equal(rho_s, rho1[sub]) and np.array_equal(fl_s, fl1[sub])
             np.testing.assert_array_equal(tr_s[:, :7], tr1[sub, :7])
     finally:
@@ -637,7 +637,7 @@ def test_downsampled_wide_cohorts_vs_oracle(oracle, p, rate, monkeypatch):
     device = _lib.Device(0)
     device.hint_downsample(rate)                         # <= 12 active columns per gene: the library picks the row-wise kernels
     device.upload(covs)
-    assert device.class_kernel_name(0) == ('k_baseline_gen' if rate == 150 else 'k_baseline_rows')   # one wavefront per gene
+    assert device.class_kernel_name(0) == ('gen::k_baseline_gen' if rate == 150 else 'gen_rows::k_baseline_gen')   # one wavefront per gene
     rho, flags, trace = device.baseline_iteration(scale, nmf_iter=30, min_high_coverage=2, downsample_rate=rate,
                                                   ds_start=offs, want_estimates=True)
     prm = oracle.make_params(nmf_iter=30, min_high_coverage=2, downsample_rate=rate)
@@ -667,7 +667,7 @@ def test_wrong_downsample_hint_grows_the_scratch(oracle):
     dev = _lib.Device(0)
     dev.hint_downsample(4000)                              # "every gene keeps one column": 64-column slots
     dev.upload(covs)
-    assert dev.class_kernel_name(0) == 'k_baseline_rows'
+    assert dev.class_kernel_name(0) == 'gen_rows::k_baseline_gen'
     rho, flags, trace = dev.baseline_iteration(scale, nmf_iter=15, min_high_coverage=2, downsample_rate=rate, ds_start=offs)
     dev.close()
     assert trace[:, 0].max() > 64                          # more active columns than the slots were sized for
@@ -694,7 +694,7 @@ def test_downsample_hint_only_changes_the_kernel_family(device, oracle):
         rho, flags, trace = dev.baseline_iteration(scale, nmf_iter=25, min_high_coverage=2, downsample_rate=rate, ds_start=offs)
         out.append((rho, flags, trace, dev.class_kernel_name(0)))
         dev.close()
-    assert out[0][3].startswith('k_baseline<10') and out[1][3] == 'k_baseline_rows'
+    assert out[0][3].startswith('k_baseline<10') and out[1][3] == 'gen_rows::k_baseline_gen'
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2][:, [0, 1, 2, 3, 5, 6]], out[1][2][:, [0, 1, 2, 3, 5, 6]])
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-9, atol=1e-11)

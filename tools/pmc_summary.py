@@ -74,7 +74,7 @@ def main():
         'kernels': {},
     }
     names = [(bench['roofline'].get('kernel'), bench['roofline'].get('genes_in_kernel'))]
-    for key in ('second_kernel', 'iteration_kernel'):
+    for key in ('second_kernel', 'concurrent_kernel', 'iteration_kernel'):
         k = bench['roofline'].get(key)
         if k and k.get('kernel'):
             names.append((k['kernel'], k.get('genes')))
