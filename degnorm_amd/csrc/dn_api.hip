@@ -80,19 +80,31 @@ const KernelSet *kernel_set_for(int p)
 // 0.1 * max(F) threshold of get_high_coverage_idx (nmf.py:66-76) needs these p numbers per gene instead of a scan of
 // the whole scaled matrix in every outer iteration (SURVEY 8(d), config-4 regime note).  One workgroup per gene.
 __global__ __launch_bounds__(256) void k_row_max(const float *__restrict__ cov, const int64_t *__restrict__ goff,
-                                                 const int32_t *__restrict__ glen, float *__restrict__ rowmax, int n, int p)
+                                                 const int32_t *__restrict__ glen, float *__restrict__ rowmax,
+                                                 int32_t *__restrict__ x16, int n, int p)
 {
+    __shared__ int ok_w[4];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int g = blockIdx.x; g < n; g += gridDim.x) {
         const int L = glen[g];
+        bool ok = true;                                    // every value a whole number in [0, 65535]: fits 16 bits exactly
         for (int i = w; i < p; i += 4) {
             const float *row = cov + goff[g] + (size_t) i * L;
             float m = row[0];
-            for (int j = lane; j < L; j += 64) m = fmaxf(m, row[j]);
+            for (int j = lane; j < L; j += 64) {
+                const float v = row[j];
+                m = fmaxf(m, v);
+                ok = ok && (v >= 0.0f) && (v <= 65535.0f) && (v == truncf(v));
+            }
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
             if (lane == 0) rowmax[(size_t) g * p + i] = m;
         }
+        const int all_ok = __all(ok);
+        if (lane == 0) ok_w[w] = all_ok;
+        __syncthreads();
+        if (threadIdx.x == 0) x16[g] = (ok_w[0] && ok_w[1] && ok_w[2] && ok_w[3]) ? 1 : 0;
+        __syncthreads();
     }
 }
 
@@ -237,6 +249,7 @@ struct dn_handle_s {
     double  *d_svec = nullptr;
     int64_t *d_svoff = nullptr;
     float   *d_rowmax = nullptr;      // n x p row maxima of the raw coverage (k_row_max at upload)
+    int32_t *d_x16 = nullptr;         // n: 1 when every count of the gene is a whole number <= 65535 (packable into 16 bits)
     // outer-update state (dn_outer_begin): clipped / corrected DI, x_weighted, x_adj, ran_baseline_selection, partial sums
     double  *d_rhoc = nullptr, *d_xw = nullptr, *d_xadj = nullptr, *d_part = nullptr, *d_pvec = nullptr;
     uint8_t *d_ran = nullptr;
@@ -292,7 +305,7 @@ static void free_device(dn_handle h)
 {
     void *ptrs[] = {h->d_cov, h->d_goff, h->d_glen, h->d_order, h->d_counter, h->d_ds, h->d_ws, h->d_rho, h->d_flags,
                     h->d_trace, h->d_kfin, h->d_emode, h->d_svec, h->d_svoff, h->d_est_sums, h->d_cov_sums,
-                    h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col, h->d_rowmax, h->d_rhoc, h->d_xw, h->d_xadj,
+                    h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col, h->d_rowmax, h->d_x16, h->d_rhoc, h->d_xw, h->d_xadj,
                     h->d_part, h->d_pvec, h->d_ran};
     for (void *q : ptrs) if (q && q != (void *) h->cls[0].d_ws) (void) hipFree(q);
     for (auto &c : h->cls) {
@@ -305,7 +318,7 @@ static void free_device(dn_handle h)
     h->d_ds = nullptr; h->d_ws = nullptr; h->d_rho = nullptr; h->d_flags = nullptr; h->d_trace = nullptr;
     h->d_kfin = nullptr; h->d_emode = nullptr; h->d_svec = nullptr; h->d_svoff = nullptr; h->d_est_sums = nullptr;
     h->d_cov_sums = nullptr; h->d_status = nullptr; h->d_est = nullptr; h->d_tile_gene = nullptr; h->d_tile_col = nullptr;
-    h->d_rowmax = nullptr;
+    h->d_rowmax = nullptr; h->d_x16 = nullptr;
     h->d_rhoc = nullptr; h->d_xw = nullptr; h->d_xadj = nullptr; h->d_part = nullptr; h->d_pvec = nullptr; h->d_ran = nullptr;
     h->n_iter = 0;
     h->have_estimate_state = false;
@@ -450,6 +463,7 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
     HIP_TRY(hipMalloc(&h->d_cov_sums, sizeof(double) * (size_t) n * p));
     HIP_TRY(hipMalloc(&h->d_status, sizeof(int32_t) * (size_t) n));
     HIP_TRY(hipMalloc(&h->d_rowmax, sizeof(float) * (size_t) n * p));
+    HIP_TRY(hipMalloc(&h->d_x16, sizeof(int32_t) * (size_t) n));
     HIP_TRY(hipMalloc(&h->d_tile_gene, sizeof(int32_t) * (size_t) std::max<int64_t>(h->n_tiles, 1)));
     HIP_TRY(hipMalloc(&h->d_tile_col, sizeof(int32_t) * (size_t) std::max<int64_t>(h->n_tiles, 1)));
 
@@ -461,7 +475,7 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
     HIP_TRY(hipMemcpyAsync(h->d_tile_gene, tg.data(), sizeof(int32_t) * tg.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_tile_col, tc.data(), sizeof(int32_t) * tc.size(), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_row_max, dim3((unsigned) std::min<int64_t>(n, (int64_t) h->n_cus * 8)), dim3(256), 0, h->stream,
-                       h->d_cov, h->d_goff, h->d_glen, h->d_rowmax, (int) n, (int) p);
+                       h->d_cov, h->d_goff, h->d_glen, h->d_rowmax, h->d_x16, (int) n, (int) p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
 
@@ -473,15 +487,15 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
         else if (narrow) {
             // Narrow class (128-thread workgroups, two genes per CU): its fixed cost per inner iteration (reduce +
             // eigen-solve, ~3.3 k cycles) is paid by half a CU instead of a whole one, so it wins for every gene it can
-            // keep mostly on chip.  On-chip columns of a narrow workgroup = register tier + LDS tier; measured optimum of
-            // the boundary on config 2 (p = 10: 1 536 + 975 on chip): 3 600-4 000 bases, i.e. ~1.5 x that capacity
-            // (split 2 047 / 2 511 / 3 100 / 3 600 / 4 000 / 4 400 -> 10 950 / 11 130 / 11 430 / 11 540 / 11 520 / 11 260
-            // genes/s).  Without a register tier: ~2.1 x the LDS columns (round 1: 2 000-2 200 at 975 columns).
+            // keep mostly on chip.  On-chip columns of a narrow workgroup = register tier + LDS tier (p = 10: 1 280 + 975);
+            // measured optimum of the boundary on config 2: 3 600-4 000 bases, i.e. ~1.7 x that capacity (split 2 600 /
+            // 3 000 / 3 400 / 3 800 / 4 200 -> 11 510 / 11 740 / 11 920 / 11 950 / 11 890 genes/s).  Without a register
+            // tier: ~2.1 x the LDS columns (round 1: 2 000-2 200 at 975 columns).
             const int per_cu_n = std::max(1, narrow->blocks_per_cu(0));
             const int64_t lds_n = (160 * 1024) / per_cu_n - (int64_t) narrow->static_lds_bytes - 256;
             const int64_t lds_cols_n = std::max<int64_t>(0, lds_n / (8 * (int64_t) (p + (p & 1))));
-            const int64_t reg_cols_n = narrow->slot_extra_bytes / (8 * (int64_t) p);       // RT * NT (the save area has one double per register pair)
-            h->split_len = (int32_t) (reg_cols_n > 0 ? (int64_t) (1.5 * (double) (reg_cols_n + lds_cols_n)) : (int64_t) (2.1 * (double) lds_cols_n));
+            const int64_t reg_cols_n = narrow->reg_tier_cols;
+            h->split_len = (int32_t) (reg_cols_n > 0 ? (int64_t) (1.7 * (double) (reg_cols_n + lds_cols_n)) : (int64_t) (2.1 * (double) lds_cols_n));
         }
         if (!narrow) h->split_len = 0;
         if (!env && p >= 25) h->split_len = 0;     // wide cohorts (MFMA Gram): one class measured 3-5 % faster than two
@@ -717,7 +731,7 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     a.ds_start = nullptr;
     a.ws = h->d_ws; a.rho = h->d_rho; a.flags = h->d_flags; a.trace = h->d_trace; a.kfin = h->d_kfin; a.emode = h->d_emode;
     a.svec = h->d_svec; a.svoff = h->d_svoff; a.slot_bytes = h->slot_bytes; a.n_genes = (int32_t) h->n; a.S = h->S;
-    a.p = h->p; a.rowmax = h->d_rowmax; a.max_steps = h->max_steps;
+    a.p = h->p; a.rowmax = h->d_rowmax; a.x16 = h->d_x16; a.max_steps = h->max_steps;
     a.T = prm->nmf_iter; a.bins = prm->bins; a.min_hc = prm->min_high_coverage; a.rate = prm->downsample_rate;
     a.skip = prm->skip_baseline_selection ? 1 : 0; a.want_est = prm->want_estimates ? 1 : 0;
     for (int i = 0; i < h->p; i++) { a.scale[i] = scale[i]; a.inv_scale[i] = 1.0 / scale[i]; h->last_scale[i] = scale[i]; }

@@ -79,6 +79,7 @@ const KernelSet *DN_CAT3(kernel_set_p, DN_P, _nt, DN_NT)()
         sizeof(Smem<DN_P, DN_NT>) + sizeof(GeneState<DN_P>),
         name,
         DN_REG_TIER ? rt_save_bytes<DN_P, DN_NT>() : 0,
+        DN_REG_TIER ? rt_cols<DN_P, true>() * DN_NT : 0,
     };
     return &ks;
 }

@@ -82,6 +82,7 @@ struct IterArgs {
     int32_t       *counter;    // queue head
     const int64_t *ds_start;   // per gene, or nullptr
     const float   *rowmax;     // n x p: max_j x[i][j] of the raw coverage (k_row_max, once per upload)
+    const int32_t *x16;        // n: every count of the gene is a whole number <= 65535 (the register tier may pack them)
     char          *ws;         // scratch: slots x slot_bytes
     double        *rho;        // n x p
     int32_t       *flags;      // n
@@ -1149,18 +1150,14 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #ifndef DN_RT_MIN_P
 #define DN_RT_MIN_P 8            // below it a workgroup needs so few registers that several share a SIMD: left alone
 #endif
-template <int P> constexpr int rt_cols()
-{
-    return (P >= DN_RT_MIN_P && P <= DN_RT_MAX_P) ? (256 / (2 * P) < DN_RT_MAX_COLS ? 256 / (2 * P) : DN_RT_MAX_COLS) : 0;
-}
 #if defined(DN_P) && DN_P >= DN_RT_MIN_P && DN_P <= DN_RT_MAX_P && !defined(DN_NO_REG_TIER)
 #define DN_REG_TIER 1
 #define DN_KERNEL_WAVES 2        // the register ALLOCATOR's budget: 512 / 2 registers (the kernel really runs one wave per SIMD)
 // The caller's view: nmf_call() visibly uses no AGPR (it must not name one in a constraint or clobber: a function that
 // visibly uses AGPRs gets half of its budget as AGPRs, 128 + 128), so inter-procedural register allocation lets
 // k_baseline park values in accumulation registers across the call.  nmf_call() therefore SAVES the registers of the
-// tier to the workgroup's scratch slot on entry and restores them on every exit (rt_save / rt_restore: 2 x 240 moves
-// and 2 x 120 coalesced 8-byte accesses per lane and call, against >= 100 passes over the gene in between).
+// tier to the workgroup's scratch slot on entry and restores them on every exit (rt_save / rt_restore: 2 x 250 moves
+// and as many 4-byte accesses per lane and call, against >= 100 passes over the gene in between).
 // k_baseline names a255 once so that the kernel descriptor asks for all 512 registers of a lane.
 #define DN_RT_CLAIM() asm volatile("" ::: "a255")
 #else
@@ -1169,84 +1166,116 @@ template <int P> constexpr int rt_cols()
 #define DN_RT_CLAIM()
 #endif
 
-// agpr_get<N>() / agpr_put<N>(v): the double held in a[N : N + 1], N even.  Register names must be literal text.
-template <int IDX> __device__ __forceinline__ double agpr_get();
-template <int IDX> __device__ __forceinline__ void agpr_put(double v);
-#define DN_AGPR_ACCESSORS(N, N1)                                                                                          \
-    template <> __device__ __forceinline__ double agpr_get<N>()                                                           \
-    {                                                                                                                     \
-        int lo, hi;                                                                                                       \
-        asm volatile("v_accvgpr_read_b32 %0, a" #N "\n\tv_accvgpr_read_b32 %1, a" #N1 : "=v"(lo), "=v"(hi));             \
-        return __hiloint2double(hi, lo);                                                                                  \
-    }                                                                                                                     \
-    template <> __device__ __forceinline__ void agpr_put<N>(double v)                                                     \
-    {                                                                                                                     \
-        asm volatile("v_accvgpr_write_b32 a" #N ", %0\n\tv_accvgpr_write_b32 a" #N1 ", %1" : : "v"(__double2loint(v)), "v"(__double2hiint(v))); \
-    }
-#define DN_AGPR_PAIRS(X) \
-    X(0, 1) X(2, 3) X(4, 5) X(6, 7) X(8, 9) X(10, 11) X(12, 13) X(14, 15) \
-    X(16, 17) X(18, 19) X(20, 21) X(22, 23) X(24, 25) X(26, 27) X(28, 29) X(30, 31) \
-    X(32, 33) X(34, 35) X(36, 37) X(38, 39) X(40, 41) X(42, 43) X(44, 45) X(46, 47) \
-    X(48, 49) X(50, 51) X(52, 53) X(54, 55) X(56, 57) X(58, 59) X(60, 61) X(62, 63) \
-    X(64, 65) X(66, 67) X(68, 69) X(70, 71) X(72, 73) X(74, 75) X(76, 77) X(78, 79) \
-    X(80, 81) X(82, 83) X(84, 85) X(86, 87) X(88, 89) X(90, 91) X(92, 93) X(94, 95) \
-    X(96, 97) X(98, 99) X(100, 101) X(102, 103) X(104, 105) X(106, 107) X(108, 109) X(110, 111) \
-    X(112, 113) X(114, 115) X(116, 117) X(118, 119) X(120, 121) X(122, 123) X(124, 125) X(126, 127) \
-    X(128, 129) X(130, 131) X(132, 133) X(134, 135) X(136, 137) X(138, 139) X(140, 141) X(142, 143) \
-    X(144, 145) X(146, 147) X(148, 149) X(150, 151) X(152, 153) X(154, 155) X(156, 157) X(158, 159) \
-    X(160, 161) X(162, 163) X(164, 165) X(166, 167) X(168, 169) X(170, 171) X(172, 173) X(174, 175) \
-    X(176, 177) X(178, 179) X(180, 181) X(182, 183) X(184, 185) X(186, 187) X(188, 189) X(190, 191) \
-    X(192, 193) X(194, 195) X(196, 197) X(198, 199) X(200, 201) X(202, 203) X(204, 205) X(206, 207) \
-    X(208, 209) X(210, 211) X(212, 213) X(214, 215) X(216, 217) X(218, 219) X(220, 221) X(222, 223) \
-    X(224, 225) X(226, 227) X(228, 229) X(230, 231) X(232, 233) X(234, 235) X(236, 237) X(238, 239) \
-    X(240, 241) X(242, 243) X(244, 245) X(246, 247) X(248, 249) X(250, 251) X(252, 253) X(254, 255)
-DN_AGPR_PAIRS(DN_AGPR_ACCESSORS)
+// agpr_get1<N>() / agpr_put1<N>(v): the 32-bit value held in aN.  Register names must be literal text, hence the list.
+template <int IDX> __device__ __forceinline__ int agpr_get1();
+template <int IDX> __device__ __forceinline__ void agpr_put1(int v);
+#define DN_AGPR_ACCESSORS(N)                                                                                              \
+    template <> __device__ __forceinline__ int agpr_get1<N>() { int v; asm volatile("v_accvgpr_read_b32 %0, a" #N : "=v"(v)); return v; } \
+    template <> __device__ __forceinline__ void agpr_put1<N>(int v) { asm volatile("v_accvgpr_write_b32 a" #N ", %0" : : "v"(v)); }
+#define DN_AGPR_REGS(X) \
+    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+    X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) \
+    X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) \
+    X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) \
+    X(64) X(65) X(66) X(67) X(68) X(69) X(70) X(71) X(72) X(73) X(74) X(75) X(76) X(77) X(78) X(79) \
+    X(80) X(81) X(82) X(83) X(84) X(85) X(86) X(87) X(88) X(89) X(90) X(91) X(92) X(93) X(94) X(95) \
+    X(96) X(97) X(98) X(99) X(100) X(101) X(102) X(103) X(104) X(105) X(106) X(107) X(108) X(109) X(110) X(111) \
+    X(112) X(113) X(114) X(115) X(116) X(117) X(118) X(119) X(120) X(121) X(122) X(123) X(124) X(125) X(126) X(127) \
+    X(128) X(129) X(130) X(131) X(132) X(133) X(134) X(135) X(136) X(137) X(138) X(139) X(140) X(141) X(142) X(143) \
+    X(144) X(145) X(146) X(147) X(148) X(149) X(150) X(151) X(152) X(153) X(154) X(155) X(156) X(157) X(158) X(159) \
+    X(160) X(161) X(162) X(163) X(164) X(165) X(166) X(167) X(168) X(169) X(170) X(171) X(172) X(173) X(174) X(175) \
+    X(176) X(177) X(178) X(179) X(180) X(181) X(182) X(183) X(184) X(185) X(186) X(187) X(188) X(189) X(190) X(191) \
+    X(192) X(193) X(194) X(195) X(196) X(197) X(198) X(199) X(200) X(201) X(202) X(203) X(204) X(205) X(206) X(207) \
+    X(208) X(209) X(210) X(211) X(212) X(213) X(214) X(215) X(216) X(217) X(218) X(219) X(220) X(221) X(222) X(223) \
+    X(224) X(225) X(226) X(227) X(228) X(229) X(230) X(231) X(232) X(233) X(234) X(235) X(236) X(237) X(238) X(239) \
+    X(240) X(241) X(242) X(243) X(244) X(245) X(246) X(247) X(248) X(249) X(250) X(251) X(252) X(253) X(254) X(255)
+DN_AGPR_REGS(DN_AGPR_ACCESSORS)
 #undef DN_AGPR_ACCESSORS
-#undef DN_AGPR_PAIRS
-
-template <int P, int R> __device__ __forceinline__ void rt_read(double (&a)[P])
+#undef DN_AGPR_REGS
+template <int IDX> __device__ __forceinline__ double agpr_get()          // the double in a[IDX : IDX + 1] (any IDX)
 {
-    static_for<0, P>([&](auto ic) { constexpr int I = decltype(ic)::value; a[I] = agpr_get<2 * (P * R + I)>(); });
+    const int lo = agpr_get1<IDX>(), hi = agpr_get1<IDX + 1>();
+    return __hiloint2double(hi, lo);
 }
-template <int P, int R> __device__ __forceinline__ void rt_write(const double (&a)[P])
+template <int IDX> __device__ __forceinline__ void agpr_put(double v)
 {
-    static_for<0, P>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put<2 * (P * R + I)>(a[I]); });
+    agpr_put1<IDX>(__double2loint(v));
+    agpr_put1<IDX + 1>(__double2hiint(v));
+}
+
+// Column r of a lane: registers [BASE, BASE + 2 P) hold the p doubles of x + lambda; with X16 the next ceil(p / 2)
+// registers hold the column's raw counts packed as 16-bit integers (exact up to 65 535; a gene with a larger count takes
+// the variant without them), so that a register-tier column needs no memory access at all in a pass.
+template <int P, int BASE> __device__ __forceinline__ void rt_read(double (&a)[P])
+{
+    static_for<0, P>([&](auto ic) { constexpr int I = decltype(ic)::value; a[I] = agpr_get<BASE + 2 * I>(); });
+}
+template <int P, int BASE> __device__ __forceinline__ void rt_write(const double (&a)[P])
+{
+    static_for<0, P>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put<BASE + 2 * I>(a[I]); });
+}
+template <int P, int BASE> __device__ __forceinline__ void rt_read_counts(double (&xd)[P])
+{
+    static_for<0, (P + 1) / 2>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        const unsigned w = (unsigned) agpr_get1<BASE + J>();
+        xd[2 * J] = (double) (w & 0xffffu);
+        if constexpr (2 * J + 1 < P) xd[2 * J + 1] = (double) (w >> 16);
+    });
+}
+template <int P, int BASE> __device__ __forceinline__ void rt_write_counts(const float (&x)[P])
+{
+    static_for<0, (P + 1) / 2>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        unsigned w = (unsigned) x[2 * J];
+        if constexpr (2 * J + 1 < P) w |= ((unsigned) x[2 * J + 1]) << 16;
+        agpr_put1<BASE + J>((int) w);
+    });
+}
+template <int P, bool X16> constexpr int rt_col_regs() { return 2 * P + (X16 ? (P + 1) / 2 : 0); }
+template <int P, bool X16> constexpr int rt_cols()
+{
+    return (P >= DN_RT_MIN_P && P <= DN_RT_MAX_P) ? (256 / rt_col_regs<P, X16>() < DN_RT_MAX_COLS ? 256 / rt_col_regs<P, X16>() : DN_RT_MAX_COLS) : 0;
+}
+template <int P> constexpr int rt_regs_used()          // registers a0 .. a(N - 1) that either variant touches
+{
+    return rt_cols<P, true>() * rt_col_regs<P, true>() > rt_cols<P, false>() * rt_col_regs<P, false>()
+               ? rt_cols<P, true>() * rt_col_regs<P, true>() : rt_cols<P, false>() * rt_col_regs<P, false>();
 }
 // The caller's contents of the tier's registers, parked in the scratch slot for the duration of one nmf() call:
 // register pair i of lane tid at save[tid * N + i]: lane-major, so that ONE address register and immediate offsets serve
 // all N accesses (register-major would be coalesced but needs N 64-bit addresses, which the compiler keeps alive -- in
 // scratch -- from the save to the restore).
-// Batches of RT_BATCH registers pairs: the loads of a batch are all in flight together (one memory latency per batch, not
-// per register), and the compiler barrier between batches keeps it from gathering every register first (120 doubles
-// would not fit next to anything else).
-constexpr int RT_BATCH = 24;
-template <int N, int NT> __device__ __forceinline__ void rt_save(double *save)
+// Batches of RT_BATCH registers: the loads of a batch are all in flight together (one memory latency per batch, not per
+// register), and the compiler barrier between batches keeps it from gathering every register first.
+constexpr int RT_BATCH = 48;
+template <int N, int NT> __device__ __forceinline__ void rt_save(int *save)
 {
     static_for<0, (N + RT_BATCH - 1) / RT_BATCH>([&](auto bc) {
         constexpr int B = decltype(bc)::value * RT_BATCH;
         constexpr int CNT = (N - B) < RT_BATCH ? (N - B) : RT_BATCH;
-        double v[CNT];
-        static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; v[I] = agpr_get<2 * (B + I)>(); });
+        int v[CNT];
+        static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; v[I] = agpr_get1<B + I>(); });
 #pragma unroll
         for (int i = 0; i < CNT; i++) save[(size_t) threadIdx.x * N + B + i] = v[i];
         asm volatile("" ::: "memory");
     });
 }
-template <int N, int NT> __device__ __forceinline__ void rt_restore(const double *save)
+template <int N, int NT> __device__ __forceinline__ void rt_restore(const int *save)
 {
     static_for<0, (N + RT_BATCH - 1) / RT_BATCH>([&](auto bc) {
         constexpr int B = decltype(bc)::value * RT_BATCH;
         constexpr int CNT = (N - B) < RT_BATCH ? (N - B) : RT_BATCH;
-        double v[CNT];
+        int v[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; i++) v[i] = save[(size_t) threadIdx.x * N + B + i];
-        static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put<2 * (B + I)>(v[I]); });
+        static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put1<B + I>(v[I]); });
         asm volatile("" ::: "memory");
     });
 }
-template <int P, int NT> constexpr size_t rt_save_bytes() { return (size_t) rt_cols<P>() * P * 8 * NT; }
+template <int P, int NT> constexpr size_t rt_save_bytes() { return (size_t) rt_regs_used<P>() * 4 * NT; }
 
-template <int P, int NT>
+template <int P, int NT, bool X16>
 __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *rs_, double *sv_,
                                          int n, int S, int nL, int T, int first_i)
 {
@@ -1289,7 +1318,8 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
     const int tid = threadIdx.x;
     constexpr bool RAW = DN_RAW_UNITS && P < DN_MG_MIN_P;  // state and Gram partials in raw count units (col_update_raw)
-    constexpr int RT = DN_REG_TIER ? rt_cols<P>() : 0;     // columns per lane held in AGPRs (register tier)
+    constexpr int RT = DN_REG_TIER ? rt_cols<P, X16>() : 0;   // columns per lane held in AGPRs (register tier)
+    constexpr int CS = rt_col_regs<P, X16>();              // registers per column: the state, and with X16 the packed raw counts
     constexpr int NR = RT * NT;                            // the gene's first NR columns
     const int nLe = (n < NR + nL) ? n : NR + nL;           // end of the LDS tier (absolute column); LDS slot of column k: k - NR
     const int kS0 = NR + nL;                               // first column of the spill tier
@@ -1352,9 +1382,13 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         constexpr int R = decltype(rc)::value;
         const int k = tid + R * NT;
         if (k < n) {
+            float xf[P];
             double f[P];
-            if constexpr (RAW) load_xd<P>(Fb, k, f); else load_f<P>(Fb, k, inv, f);
-            rt_write<P, R>(f);
+            load_x<P>(Fb, k, xf);
+#pragma unroll
+            for (int i = 0; i < P; i++) f[i] = RAW ? (double) xf[i] : (double) xf[i] * inv[i];
+            rt_write<P, CS * R>(f);
+            if constexpr (X16) rt_write_counts<P, CS * R + 2 * P>(xf);
         }
     });
     for (int k = NR + tid; k < nLe; k += NT) {
@@ -1388,7 +1422,25 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         // -- and so did a register-resident tier in front of it (tools/trace_stats.py, profiles/round1).
         // register tier: unrolled over the lane's RT columns, the next column's counts requested before this one's arithmetic
         auto reg_tier = [&]() {
-            if constexpr (RT > 0) {
+            if constexpr (RT > 0 && X16) {
+                // counts AND state in registers: a column of this tier touches no memory in a pass
+                static_for<0, RT>([&](auto rc) {
+                    constexpr int R = decltype(rc)::value;
+                    const int k = tid + R * NT;
+                    if (k < n) {
+                        double f[P], a[P];
+                        rt_read_counts<P, CS * R + 2 * P>(f);
+                        if constexpr (!RAW) {
+#pragma unroll
+                            for (int i = 0; i < P; i++) f[i] *= inv[i];
+                        }
+                        rt_read<P, CS * R>(a);
+                        if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
+                        gram_add_range<P, 0, CH>(G, a);
+                        rt_write<P, CS * R>(a);
+                    }
+                });
+            } else if constexpr (RT > 0) {
                 // the next column's counts are requested before this column's arithmetic starts (two columns ahead with two
                 // buffers measured no faster: 341.9 vs 339.0 ms per sweep)
                 float xq[P];
@@ -1401,10 +1453,10 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #pragma unroll
                         for (int i = 0; i < P; i++) f[i] = RAW ? (double) xq[i] : (double) xq[i] * inv[i];
                         if constexpr (R + 1 < RT) load_x<P>(Fb, k + NT < n ? k + NT : k, xq);
-                        rt_read<P, R>(a);
+                        rt_read<P, CS * R>(a);
                         if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
                         gram_add_range<P, 0, CH>(G, a);
-                        rt_write<P, R>(a);
+                        rt_write<P, CS * R>(a);
                     }
                 });
             }
@@ -1529,7 +1581,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         const int k = tid + R * NT;
         if (k < n) {
             double l[P];
-            rt_read<P, R>(l);
+            rt_read<P, CS * R>(l);
             fin(k, l);
         }
     });
@@ -1567,15 +1619,18 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 // independent of what the state machine keeps live.
 template <int P, int NT>
 __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_, double *rs_, double *sv_, double *rtsave_,
-                                                   int n, int S, int nL, int T, int first_i)
+                                                   int n, int S, int nL, int T, int first_i, int x16_i)
 {
-    constexpr int NSAVE = DN_REG_TIER ? rt_cols<P>() * P : 0;
-    double *rtsave = uniform_ptr(rtsave_);
+    constexpr int NSAVE = DN_REG_TIER ? rt_regs_used<P>() : 0;
+    int *rtsave = reinterpret_cast<int *>(uniform_ptr(rtsave_));
 #ifdef DN_STAMP
     const long long t_call0 = __builtin_amdgcn_s_memtime();
 #endif
     rt_save<NSAVE, NT>(rtsave);
-    nmf_body<P, NT>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+    // counts up to 65 535 are carried in the register tier next to the state (X16); a gene with a larger count runs the
+    // variant that reads them from the scratch slot (two more state columns per lane instead)
+    if (DN_REG_TIER && __builtin_amdgcn_readfirstlane(x16_i) != 0) nmf_body<P, NT, (DN_REG_TIER != 0)>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+    else nmf_body<P, NT, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     rt_restore<NSAVE, NT>(rtsave);
 #ifdef DN_STAMP
     if (threadIdx.x == 0) g_gs.stamp[3] += __builtin_amdgcn_s_memtime() - t_call0;
@@ -1653,12 +1708,14 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
         // max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): division by a positive scalar is monotone, so the global maximum
         // of the scaled matrix needs only the p row maxima of the RAW counts, computed once per upload (k_row_max).
         double thr;
+        int x16;
         {
             const float *rmx = A.rowmax + (size_t) g * P;
             double gmax = (double) rmx[0] / A.scale[0];
 #pragma unroll
             for (int i = 1; i < P; i++) { const double v = (double) rmx[i] / A.scale[i]; gmax = v > gmax ? v : gmax; }
             thr = 0.1 * gmax;
+            x16 = A.x16[g];                                          // every raw count of the gene is a whole number that fits 16 bits
         }
 
         // Candidate columns: every base, or -- when down-sampling -- only the systematic sample ds0 + m * rate
@@ -1733,7 +1790,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                 // One nmf() call per trip: the first on F_start (nmf.py:245), the others inside the
                 // `while max(rho) > 0.1` loop of nmf.py:273-324 after a bin has been dropped.
                 for (;;) {
-                    nmf_call<P, NT>(Fb, Lg, rs, sv, rtsave, n, S, nL, A.T, first ? 1 : 0);       // results in gs (LDS)
+                    nmf_call<P, NT>(Fb, Lg, rs, sv, rtsave, n, S, nL, A.T, first ? 1 : 0, x16);       // results in gs (LDS)
                     if (gs.status != ST_OK) { status = gs.status; break; }
                     const double *u = gs.u, *sums = gs.sums;
                     const double theta = gs.theta;
@@ -2043,6 +2100,7 @@ struct KernelSet {
     size_t static_lds_bytes;          // static LDS of k_baseline
     const char *baseline_name;
     size_t slot_extra_bytes;          // per scratch slot, behind the S-sized arrays (register-tier save area)
+    int reg_tier_cols;                // columns of a gene a workgroup keeps in registers (0: no register tier)
 };
 
 const KernelSet *kernel_set_for(int p);   // dn_api.hip
