@@ -1249,28 +1249,34 @@ template <int P> constexpr int rt_regs_used()          // registers a0 .. a(N - 
 // Batches of RT_BATCH registers: the loads of a batch are all in flight together (one memory latency per batch, not per
 // register), and the compiler barrier between batches keeps it from gathering every register first.
 constexpr int RT_BATCH = 48;
-template <int N, int NT> __device__ __forceinline__ void rt_save(int *save)
+// `need`: registers a0 .. a(need - 1) are the only ones this call can write (columns beyond the gene's width are never
+// touched), so only whole batches below it are parked.
+template <int N, int NT> __device__ __forceinline__ void rt_save(int *save, int need)
 {
     static_for<0, (N + RT_BATCH - 1) / RT_BATCH>([&](auto bc) {
         constexpr int B = decltype(bc)::value * RT_BATCH;
         constexpr int CNT = (N - B) < RT_BATCH ? (N - B) : RT_BATCH;
-        int v[CNT];
-        static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; v[I] = agpr_get1<B + I>(); });
+        if (B < need) {
+            int v[CNT];
+            static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; v[I] = agpr_get1<B + I>(); });
 #pragma unroll
-        for (int i = 0; i < CNT; i++) save[(size_t) threadIdx.x * N + B + i] = v[i];
-        asm volatile("" ::: "memory");
+            for (int i = 0; i < CNT; i++) save[(size_t) threadIdx.x * N + B + i] = v[i];
+            asm volatile("" ::: "memory");
+        }
     });
 }
-template <int N, int NT> __device__ __forceinline__ void rt_restore(const int *save)
+template <int N, int NT> __device__ __forceinline__ void rt_restore(const int *save, int need)
 {
     static_for<0, (N + RT_BATCH - 1) / RT_BATCH>([&](auto bc) {
         constexpr int B = decltype(bc)::value * RT_BATCH;
         constexpr int CNT = (N - B) < RT_BATCH ? (N - B) : RT_BATCH;
-        int v[CNT];
+        if (B < need) {
+            int v[CNT];
 #pragma unroll
-        for (int i = 0; i < CNT; i++) v[i] = save[(size_t) threadIdx.x * N + B + i];
-        static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put1<B + I>(v[I]); });
-        asm volatile("" ::: "memory");
+            for (int i = 0; i < CNT; i++) v[i] = save[(size_t) threadIdx.x * N + B + i];
+            static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put1<B + I>(v[I]); });
+            asm volatile("" ::: "memory");
+        }
     });
 }
 template <int P, int NT> constexpr size_t rt_save_bytes() { return (size_t) rt_regs_used<P>() * 4 * NT; }
@@ -1429,15 +1435,30 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                     const int k = tid + R * NT;
                     if (k < n) {
                         double f[P], a[P];
+#if defined(DN_STAMP) && defined(DN_EXP_PHASE)      // diagnostic: cycles of ONE phase of column 0 (DN_EXP_PHASE = 1 reads, 2 update, 3 Gram, 4 writes) into stamp[2]
+#define DN_PH0(ph) long long tph_ = 0; if (R == 0 && DN_EXP_PHASE == ph) tph_ = __builtin_amdgcn_s_memtime()
+#define DN_PH1(ph) if (R == 0 && DN_EXP_PHASE == ph) stamp[2] += __builtin_amdgcn_s_memtime() - tph_
+#else
+#define DN_PH0(ph)
+#define DN_PH1(ph)
+#endif
+                        { DN_PH0(1);
                         rt_read_counts<P, CS * R + 2 * P>(f);
                         if constexpr (!RAW) {
 #pragma unroll
                             for (int i = 0; i < P; i++) f[i] *= inv[i];
                         }
                         rt_read<P, CS * R>(a);
+                        DN_PH1(1); }
+                        { DN_PH0(2);
                         if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
+                        DN_PH1(2); }
+                        { DN_PH0(3);
                         gram_add_range<P, 0, CH>(G, a);
+                        DN_PH1(3); }
+                        { DN_PH0(4);
                         rt_write<P, CS * R>(a);
+                        DN_PH1(4); }
                     }
                 });
             } else if constexpr (RT > 0) {
@@ -1556,7 +1577,10 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             u[i] = uniform(u[i]);
             if constexpr (RAW) { uw[i] = uniform(u[i] * inv[i]); uv[i] = uniform(c * u[i] * g_gs.scl[i]); }
         }
-        DN_T1(2); }
+#ifndef DN_EXP_PHASE
+        DN_T1(2);
+#endif
+        }
     }
     }   // narrow cohorts
 
@@ -1626,12 +1650,15 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
 #ifdef DN_STAMP
     const long long t_call0 = __builtin_amdgcn_s_memtime();
 #endif
-    rt_save<NSAVE, NT>(rtsave);
+    // columns of the tier this gene can reach: ceil(n / NT); their registers in the wider of the two layouts
+    const int n_u = __builtin_amdgcn_readfirstlane(n);
+    const int need = DN_REG_TIER ? ((n_u + NT - 1) / NT) * rt_col_regs<P, true>() : 0;
+    rt_save<NSAVE, NT>(rtsave, need);
     // counts up to 65 535 are carried in the register tier next to the state (X16); a gene with a larger count runs the
     // variant that reads them from the scratch slot (two more state columns per lane instead)
     if (DN_REG_TIER && __builtin_amdgcn_readfirstlane(x16_i) != 0) nmf_body<P, NT, (DN_REG_TIER != 0)>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     else nmf_body<P, NT, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
-    rt_restore<NSAVE, NT>(rtsave);
+    rt_restore<NSAVE, NT>(rtsave, need);
 #ifdef DN_STAMP
     if (threadIdx.x == 0) g_gs.stamp[3] += __builtin_amdgcn_s_memtime() - t_call0;
 #endif
