@@ -929,20 +929,27 @@ int dn_fetch_estimates_subset(dn_handle h, int64_t n_sel, const int64_t *gene_id
         for (int32_t c = 0; c < h->glen[g]; c += 256) { tg.push_back((int32_t) g); tc.push_back(c); }
     }
     double *d_out = nullptr; int64_t *d_ooff = nullptr; int32_t *d_tg = nullptr, *d_tc = nullptr;
-    HIP_TRY(hipMalloc(&d_out, sizeof(double) * (size_t) total));
-    HIP_TRY(hipMalloc(&d_ooff, sizeof(int64_t) * (size_t) h->n));
-    HIP_TRY(hipMalloc(&d_tg, sizeof(int32_t) * tg.size()));
-    HIP_TRY(hipMalloc(&d_tc, sizeof(int32_t) * tc.size()));
-    HIP_TRY(hipMemcpyAsync(d_ooff, ooff.data(), sizeof(int64_t) * (size_t) h->n, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_tg, tg.data(), sizeof(int32_t) * tg.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_tc, tc.data(), sizeof(int32_t) * tc.size(), hipMemcpyHostToDevice, h->stream));
+    hipError_t le = hipMalloc(&d_out, sizeof(double) * (size_t) total);            // nothing leaks on a failure half-way
+    if (le == hipSuccess) le = hipMalloc(&d_ooff, sizeof(int64_t) * (size_t) h->n);
+    if (le == hipSuccess) le = hipMalloc(&d_tg, sizeof(int32_t) * tg.size());
+    if (le == hipSuccess) le = hipMalloc(&d_tc, sizeof(int32_t) * tc.size());
+    if (le == hipSuccess) le = hipMemcpyAsync(d_ooff, ooff.data(), sizeof(int64_t) * (size_t) h->n, hipMemcpyHostToDevice, h->stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(d_tg, tg.data(), sizeof(int32_t) * tg.size(), hipMemcpyHostToDevice, h->stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(d_tc, tc.data(), sizeof(int32_t) * tc.size(), hipMemcpyHostToDevice, h->stream);
+    if (le != hipSuccess) {
+        if (d_out) (void) hipFree(d_out);
+        if (d_ooff) (void) hipFree(d_ooff);
+        if (d_tg) (void) hipFree(d_tg);
+        if (d_tc) (void) hipFree(d_tc);
+        return fail(DN_E_HIP, std::string("dn_fetch_estimates_subset: ") + hipGetErrorString(le));
+    }
     dn::EstArgs a;
     std::memset(&a, 0, sizeof(a));
     a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.kfin = h->d_kfin; a.emode = h->d_emode;
     a.svec = h->d_svec; a.svoff = h->d_svoff; a.out = d_out; a.ooff = d_ooff; a.n_genes = (int32_t) h->n; a.p = h->p;
     for (int i = 0; i < dn::P_MAX; i++) a.scale[i] = i < h->p ? h->last_scale[i] : 1.0;
     h->ks->est(a, d_tg, d_tc, (int) tg.size(), h->stream);
-    hipError_t le = hipGetLastError();
+    le = hipGetLastError();
     if (le == hipSuccess) le = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t) total, hipMemcpyDeviceToHost, h->stream);
     if (le == hipSuccess) le = hipStreamSynchronize(h->stream);
     (void) hipFree(d_out); (void) hipFree(d_ooff); (void) hipFree(d_tg); (void) hipFree(d_tc);
