@@ -199,6 +199,9 @@ def main():
     ap.add_argument('--nmf-iter', type=int, default=100)
     ap.add_argument('--cpu-sample', type=int, default=-1, help='genes in the CPU-baseline sample (0 = skip; default 768 / 2048)')
     ap.add_argument('--parity-genes', type=int, default=160, help='genes in the post-clock parity sample (0 = skip)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='collective backend under torchrun: nccl = RCCL (the measured path); gloo only to rehearse N > 1 on ONE GPU '
+                         '(every rank on device 0; the line is then marked "rehearsal")')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -214,16 +217,23 @@ def main():
     from degnorm_amd.nmf_mpi import ShardedNMFOA, TorchComm, LocalComm
     from degnorm_amd.utils import partition_by_length
 
+    rehearsal = args.backend == 'gloo'
+    if rehearsal:
+        local_rank = 0                                                  # all ranks share the one GPU
     torch.cuda.set_device(local_rank)
     comm = LocalComm()
     distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ     # under torchrun use RCCL even at N = 1
     rccl = None
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        comm = TorchComm(device='cuda:{0}'.format(local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo')
+            comm = TorchComm(device='cpu')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            comm = TorchComm(device='cuda:{0}'.format(local_rank))
         rccl = {'backend': dist.get_backend(), 'rccl_ranks': dist.get_world_size(),
-                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version())}
+                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()), 'rehearsal_on_one_gpu': rehearsal}
 
     cfg = dict(synth.CONFIGS[args.config])
     p = cfg['p']
@@ -278,7 +288,7 @@ def main():
     dt = time.time() - t0
 
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if rehearsal else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
