@@ -1726,6 +1726,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
         long long sum_cols = 0;
 #ifdef DN_STAMP
         const long long t_gene0 = __builtin_amdgcn_s_memtime();
+        long long t_ret = 0, t_book = 0;
 #endif
         int32_t *tr = A.trace + (size_t) g * TRACE_LEN;
         if (tid < P) { gs.rho[tid] = 0.0; gs.K[tid] = 0.0; gs.us[tid] = 0.0; }
@@ -1806,6 +1807,9 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
             __syncthreads();
         }
 
+#ifdef DN_STAMP
+        const long long t_scan1 = __builtin_amdgcn_s_memtime();       // end of the candidate scan + compaction
+#endif
         int n = n0;                   // current width of Fb
         if (n0 >= A.min_hc) {
             if (!(lds_min<P>(gs.sumF) > 0.0)) exit_code = EXIT_ZERO_SAMPLE;            // nmf.py:241
@@ -1817,7 +1821,13 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                 // One nmf() call per trip: the first on F_start (nmf.py:245), the others inside the
                 // `while max(rho) > 0.1` loop of nmf.py:273-324 after a bin has been dropped.
                 for (;;) {
+#ifdef DN_STAMP
+                    if (t_ret != 0) t_book += __builtin_amdgcn_s_memtime() - t_ret;      // between two nmf() calls
+#endif
                     nmf_call<P, NT>(Fb, Lg, rs, sv, rtsave, n, S, nL, A.T, first ? 1 : 0, x16);       // results in gs (LDS)
+#ifdef DN_STAMP
+                    t_ret = __builtin_amdgcn_s_memtime();
+#endif
                     if (gs.status != ST_OK) { status = gs.status; break; }
                     const double *u = gs.u, *sums = gs.sums;
                     const double theta = gs.theta;
@@ -1873,10 +1883,18 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                     flag = 1;                                                                    // nmf.py:276
                     loop_reason = LOOP_NATURAL;
                     // per-bin mean of rs[] (nmf.py:283): one wave per bin, fixed order
+                    // (the loads of four 64-column strips are issued together, then added in the order a one-by-one walk would
+                    // use: the profile is in the scratch slot, and a dependent load -> add chain paid its latency per strip)
                     for (int b = w; b < n_bins; b += W) {
                         const int kb = b * csize, ke = (kb + csize < n) ? kb + csize : n;
                         double part = 0.0;
-                        for (int k = kb + lane; k < ke; k += 64) part += rs[k];
+                        for (int k = kb + lane; k < ke; k += 4 * 64) {
+                            double v[4];
+#pragma unroll
+                            for (int c = 0; c < 4; c++) v[c] = (k + 64 * c < ke) ? rs[k + 64 * c] : 0.0;
+#pragma unroll
+                            for (int c = 0; c < 4; c++) if (k + 64 * c < ke) part += v[c];
+                        }
                         part = wave_sum1(part);
                         if (lane == 0) sm.ss[b] = part / (double) (ke - kb);
                     }
@@ -1896,11 +1914,25 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                     n -= dlen;
                     n_drops++;
                     __syncthreads();
-                    for (int k = tid; k < n; k += NT) {
-                        const int a = k / csize;
-                        const int ko = sm.alive[a] * csize + (k - a * csize);
+                    // columns in front of the dropped bin keep their place; the others are fetched again from the pristine
+                    // copy, four columns per thread in flight
+                    for (int k0 = kb + tid; k0 < n; k0 += 4 * NT) {
+                        float v[4][P];
 #pragma unroll
-                        for (int i = 0; i < P; i++) Fb[(size_t) k * P + i] = Fs[(size_t) i * S + ko];
+                        for (int c = 0; c < 4; c++) {
+                            const int k = (k0 + c * NT < n) ? k0 + c * NT : k0;
+                            const int a = k / csize;
+                            const int ko = sm.alive[a] * csize + (k - a * csize);
+#pragma unroll
+                            for (int i = 0; i < P; i++) v[c][i] = Fs[(size_t) i * S + ko];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            if (k0 + c * NT < n) {
+#pragma unroll
+                                for (int i = 0; i < P; i++) Fb[(size_t) (k0 + c * NT) * P + i] = v[c][i];
+                            }
+                        }
                     }
                     __syncthreads();
                     if (n < 2) { loop_reason = LOOP_VALUE_ERROR; break; }                        // svds ValueError, nmf.py:306-310
@@ -1986,6 +2018,9 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
             tr[40] = (int32_t) (gs.stamp[0] >> 10); tr[41] = (int32_t) (gs.stamp[1] >> 10); tr[42] = (int32_t) (gs.stamp[2] >> 10);
             tr[44] = (int32_t) (gs.stamp[3] >> 10); tr[45] = (int32_t) (gs.stamp[4] >> 10); tr[46] = (int32_t) (gs.stamp[5] >> 10);
             tr[43] = (int32_t) ((__builtin_amdgcn_s_memtime() - t_gene0) >> 10);
+            tr[47] = (int32_t) ((t_scan1 - t_gene0) >> 10);
+            tr[39] = (int32_t) (t_book >> 10);
+            tr[38] = (int32_t) ((t_ret != 0 ? __builtin_amdgcn_s_memtime() - t_ret : 0) >> 10);
 #endif
         }
         if (A.want_est && (emode == EM_CLAMPED || emode == EM_RAW)) {

@@ -53,6 +53,9 @@ if tr[:, 44:47].any():
     inner = tr[:, 40:43].astype(float).sum() * 1024
     print('share of gene time: pass+reduce+eigen %.3f | nmf() calls %.3f (cold start %.3f, final pass %.3f, save/restore+rest %.3f) | outside nmf() %.3f'
           % (inner / tot, ext[0] / tot, ext[2] / tot, ext[1] / tot, (ext[0] - inner - ext[1] - ext[2]) / tot, 1 - ext[0] / tot))
+    if tr[:, 47].any():
+        print('candidate scan + compaction: %.3f of gene time; between nmf() calls %.3f; after the last call %.3f' % (
+            tr[:, 47].astype(float).sum() * 1024 / tot, tr[:, 39].astype(float).sum() * 1024 / tot, tr[:, 38].astype(float).sum() * 1024 / tot))
     # utilisation of the resident workgroups: sum of per-gene cycles / (slots x kernel wall)
     for c in (0, 1):
         ms = dev.class_kernel_ms(c)
