@@ -1147,6 +1147,12 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #ifndef DN_RT_MAX_P
 #define DN_RT_MAX_P 12           // above it the Gram accumulators alone need more than 256 registers
 #endif
+#ifndef DN_RT_STRAIGHT
+#define DN_RT_STRAIGHT 1         // genes that fill the register tier walk it as straight-line code (no per-column exec mask)
+#endif
+#ifndef DN_RT_COLUMN_FENCE
+#define DN_RT_COLUMN_FENCE 1     // scheduling barrier between the columns of the straight-line walk
+#endif
 #ifndef DN_RT_MIN_P
 #define DN_RT_MIN_P 8            // below it a workgroup needs so few registers that several share a SIMD: left alone
 #endif
@@ -1281,7 +1287,8 @@ template <int N, int NT> __device__ __forceinline__ void rt_restore(const int *s
 }
 template <int P, int NT> constexpr size_t rt_save_bytes() { return (size_t) rt_regs_used<P>() * 4 * NT; }
 
-template <int P, int NT, bool X16>
+// FULL: the gene fills the register tier (n >= RT * NT): every lane owns all RT columns and the tier is walked as straight-line code
+template <int P, int NT, bool X16, bool FULL = false>
 __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *rs_, double *sv_,
                                          int n, int S, int nL, int T, int first_i)
 {
@@ -1341,11 +1348,17 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #endif
 #pragma unroll
     for (int i = 0; i < CH; i++) G[i] = 0.0;
+    {
+        float xq[P];                                                  // the next column's counts fly during this column's products
+        if (tid < n) load_x<P>(Fb, tid, xq);
 #pragma clang loop unroll(disable)
-    for (int k = tid; k < n; k += NT) {
-        double f[P];
-        if constexpr (RAW) load_xd<P>(Fb, k, f); else load_f<P>(Fb, k, inv, f);
-        gram_add_range<P, 0, CH>(G, f);
+        for (int k = tid; k < n; k += NT) {
+            double f[P];
+#pragma unroll
+            for (int i = 0; i < P; i++) f[i] = RAW ? (double) xq[i] : (double) xq[i] * inv[i];
+            load_x<P>(Fb, k + NT < n ? k + NT : k, xq);
+            gram_add_range<P, 0, CH>(G, f);
+        }
     }
     block_sum_lds<CH, P, NT, gram_t, false, 0, RAW>(G, sm);
     static_for<1, SW>([&](auto qc) {
@@ -1430,11 +1443,9 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         auto reg_tier = [&]() {
             if constexpr (RT > 0 && X16) {
                 // counts AND state in registers: a column of this tier touches no memory in a pass
-                static_for<0, RT>([&](auto rc) {
+                auto column = [&](auto rc) {
                     constexpr int R = decltype(rc)::value;
-                    const int k = tid + R * NT;
-                    if (k < n) {
-                        double f[P], a[P];
+                    double f[P], a[P];
 #if defined(DN_STAMP) && defined(DN_EXP_PHASE)      // diagnostic: cycles of ONE phase of column 0 (DN_EXP_PHASE = 1 reads, 2 update, 3 Gram, 4 writes) into stamp[2]
 #define DN_PH0(ph) long long tph_ = 0; if (R == 0 && DN_EXP_PHASE == ph) tph_ = __builtin_amdgcn_s_memtime()
 #define DN_PH1(ph) if (R == 0 && DN_EXP_PHASE == ph) stamp[2] += __builtin_amdgcn_s_memtime() - tph_
@@ -1442,25 +1453,35 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #define DN_PH0(ph)
 #define DN_PH1(ph)
 #endif
-                        { DN_PH0(1);
-                        rt_read_counts<P, CS * R + 2 * P>(f);
-                        if constexpr (!RAW) {
+                    { DN_PH0(1);
+                    rt_read_counts<P, CS * R + 2 * P>(f);
+                    if constexpr (!RAW) {
 #pragma unroll
-                            for (int i = 0; i < P; i++) f[i] *= inv[i];
-                        }
-                        rt_read<P, CS * R>(a);
-                        DN_PH1(1); }
-                        { DN_PH0(2);
-                        if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
-                        DN_PH1(2); }
-                        { DN_PH0(3);
-                        gram_add_range<P, 0, CH>(G, a);
-                        DN_PH1(3); }
-                        { DN_PH0(4);
-                        rt_write<P, CS * R>(a);
-                        DN_PH1(4); }
+                        for (int i = 0; i < P; i++) f[i] *= inv[i];
                     }
-                });
+                    rt_read<P, CS * R>(a);
+                    DN_PH1(1); }
+                    { DN_PH0(2);
+                    if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
+                    DN_PH1(2); }
+                    { DN_PH0(3);
+                    gram_add_range<P, 0, CH>(G, a);
+                    DN_PH1(3); }
+                    { DN_PH0(4);
+                    rt_write<P, CS * R>(a);
+                    DN_PH1(4); }
+                };
+                if constexpr (FULL) {
+                    // every lane owns all RT columns: one straight line of code, no exec mask and no branch per column (the
+                    // per-column mask costs ~90 cycles per column at one wave per SIMD: tools/ubench/clock_issue.hip); the
+                    // scheduling barrier keeps the columns apart so that the register pressure stays that of one column
+                    static_for<0, RT>([&](auto rc) { column(rc); if (DN_RT_COLUMN_FENCE) __builtin_amdgcn_sched_barrier(0); });
+                } else {
+                    static_for<0, RT>([&](auto rc) {
+                        constexpr int R = decltype(rc)::value;
+                        if (tid + R * NT < n) column(rc);
+                    });
+                }
             } else if constexpr (RT > 0) {
                 // the next column's counts are requested before this column's arithmetic starts (two columns ahead with two
                 // buffers measured no faster: 341.9 vs 339.0 ms per sweep)
@@ -1540,9 +1561,17 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                 for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], spill_ptr<P>(Lg, k) + i * 64);
             }
         };
-        if (dir > 0) { reg_tier(); lds_tier(); spill_tier(); }
-        else { spill_tier(); lds_tier(); reg_tier(); }
-        DN_T1(0); }
+#if defined(DN_STAMP) && defined(DN_EXP_TIER)           // diagnostic: only tier DN_EXP_TIER (1 register, 2 LDS, 3 spill) is timed into the pass slot
+#define DN_TIER(id, call) do { if (DN_EXP_TIER == id) { const long long tt_ = __builtin_amdgcn_s_memtime(); call; stamp[0] += __builtin_amdgcn_s_memtime() - tt_; } else { call; } } while (0)
+#else
+#define DN_TIER(id, call) call
+#endif
+        if (dir > 0) { DN_TIER(1, reg_tier()); DN_TIER(2, lds_tier()); DN_TIER(3, spill_tier()); }
+        else { DN_TIER(3, spill_tier()); DN_TIER(2, lds_tier()); DN_TIER(1, reg_tier()); }
+#if !(defined(DN_STAMP) && defined(DN_EXP_TIER))
+        DN_T1(0);
+#endif
+        }
         { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED, 0, RAW>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
         // later sweeps (p >= 16): the remaining Gram entries from the updated state, read-only
         static_for<1, SW>([&](auto qc) {
@@ -1591,9 +1620,8 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     double acc[2 * P + 1];
 #pragma unroll
     for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
-    auto fin = [&](int k, const double (&l0)[P]) {
-        double f[P], l[P], s, r;
-        load_f<P>(Fb, k, inv, f);
+    auto fin = [&](int k, const double (&f)[P], const double (&l0)[P]) {
+        double l[P], s, r;
 #pragma unroll
         for (int i = 0; i < P; i++) l[i] = RAW ? l0[i] * inv[i] : l0[i];          // back to the reference's scaled units
         col_final<P>(f, l, u, first, acc, s, r);
@@ -1604,14 +1632,24 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         constexpr int R = decltype(rc)::value;
         const int k = tid + R * NT;
         if (k < n) {
-            double l[P];
+            double f[P], l[P];
+            if constexpr (X16) {
+                rt_read_counts<P, CS * R + 2 * P>(f);
+#pragma unroll
+                for (int i = 0; i < P; i++) f[i] *= inv[i];
+            } else load_f<P>(Fb, k, inv, f);
             rt_read<P, CS * R>(l);
-            fin(k, l);
+            fin(k, f, l);
         }
     });
+    float xqf[P];
+    if (NR + tid < n) load_x<P>(Fb, NR + tid, xqf);
 #pragma clang loop unroll(disable)
     for (int k = NR + tid; k < n; k += NT) {
-        double l[P];
+        double f[P], l[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) f[i] = (double) xqf[i] * inv[i];
+        load_x<P>(Fb, k + NT < n ? k + NT : k, xqf);
         if (k < nLe) {
             double al[PS];
             lds_col_read<PS>(lam + (size_t) (k - NR) * PS, al);
@@ -1621,7 +1659,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #pragma unroll
             for (int i = 0; i < P; i++) l[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
         }
-        fin(k, l);
+        fin(k, f, l);
     }
     block_sum_lds<2 * P + 1, P, NT, double>(acc, sm);
     for (int e = tid; e < 2 * P + 1; e += NT) g_gs.sums[e] = sm.tot[e];      // 2 p + 1 can exceed the workgroup (p = 64, 128 threads)
@@ -1656,8 +1694,13 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     rt_save<NSAVE, NT>(rtsave, need);
     // counts up to 65 535 are carried in the register tier next to the state (X16); a gene with a larger count runs the
     // variant that reads them from the scratch slot (two more state columns per lane instead)
-    if (DN_REG_TIER && __builtin_amdgcn_readfirstlane(x16_i) != 0) nmf_body<P, NT, (DN_REG_TIER != 0)>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
-    else nmf_body<P, NT, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+    if (DN_REG_TIER && __builtin_amdgcn_readfirstlane(x16_i) != 0) {
+        // a third body for the genes that fill the register tier: a second variant of the tier INSIDE one body costs registers
+        // the pass does not have (the allocator starts spilling Gram accumulators in the loop)
+        constexpr bool X = DN_REG_TIER != 0;
+        if (DN_RT_STRAIGHT && X && n_u >= rt_cols<P, X>() * NT) nmf_body<P, NT, X, X && (DN_RT_STRAIGHT != 0)>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+        else nmf_body<P, NT, X, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+    } else nmf_body<P, NT, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     rt_restore<NSAVE, NT>(rtsave, need);
 #ifdef DN_STAMP
     if (threadIdx.x == 0) g_gs.stamp[3] += __builtin_amdgcn_s_memtime() - t_call0;

@@ -13,7 +13,7 @@
 // MODE >= 4 keeps a column's state in a200 .. a219 by inline asm, behind the compiler's back: its own AGPR use (spill
 // slots, allocated from a0 upwards) must stay below a200 -- check with the scan of the generated ISA before running
 template <int MODE, int NT>
-__global__ __launch_bounds__(NT) void k(double *sink, long long *stamps, int iters)
+__global__ __launch_bounds__(NT) void k(double *sink, long long *stamps, int iters, int nlim)
 {
     double a[16], b[16];
     for (int i = 0; i < 16; i++) { a[i] = threadIdx.x * 1e-3 + i; b[i] = 1.0 + 1e-9 * (threadIdx.x + i); }
@@ -35,9 +35,10 @@ __global__ __launch_bounds__(NT) void k(double *sink, long long *stamps, int ite
         } else if (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < 16; i++) a[i] = fma(b[i], b[(i + 5) & 15], a[i]);
-        } else if (MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7) {
+        } else if (MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7 || MODE == 8) {
 #pragma unroll
           for (int rep = 0; rep < (MODE >= 6 ? 10 : 1); rep++) {
+            if (MODE == 8 && !((int) threadIdx.x + rep * 256 < nlim)) continue;       // the kernel's per-column exec mask (never false here)
             // the scaled column with its state in AGPRs: 20 v_accvgpr_read before, 20 v_accvgpr_write after (MODE 5: reads only)
             double f[10], s0 = 0.0, s1 = 0.0;
             int lo[10], hi[10];
@@ -131,18 +132,19 @@ int main()
 {
     double *d; hipMalloc(&d, 64);
     long long *st; hipMalloc(&st, sizeof(long long) * 2 * 256 * 16);
-    const char *names[] = {"v_fma_f64, 1 VGPR source", "v_fma_f64, 3 VGPR sources", "column of the p=10 pass (125 instr)", "column, raw units (115 instr)", "column + 20 accvgpr reads + 20 writes (165)", "column + 20 accvgpr reads (145)", "10 unrolled copies of column + reads + writes (1650)", "the same, waves out of phase"};
-    const double per_iter[] = {16.0, 16.0, 125.0, 115.0, 165.0, 145.0, 1650.0, 1650.0};
-    for (int mode = 0; mode < 8; mode++)
+    const char *names[] = {"v_fma_f64, 1 VGPR source", "v_fma_f64, 3 VGPR sources", "column of the p=10 pass (125 instr)", "column, raw units (115 instr)", "column + 20 accvgpr reads + 20 writes (165)", "column + 20 accvgpr reads (145)", "10 unrolled copies of column + reads + writes (1650)", "the same, waves out of phase", "10 unrolled copies, each under the per-column exec mask"};
+    const double per_iter[] = {16.0, 16.0, 125.0, 115.0, 165.0, 145.0, 1650.0, 1650.0, 1650.0};
+    for (int mode = 0; mode < 9; mode++)
         for (int wps = 1; wps <= 4; wps *= 2) {
             if (mode >= 2 && wps > 2) continue;            // the column body needs > 128 registers
+            if (mode >= 4 && wps > 1) continue;            // a200 .. a219 exist only at one wave per SIMD
             const int threads = 256 * wps;
             const int iters = mode >= 6 ? 4000 : (mode >= 2 ? 40000 : 300000);          // a few ms per launch; three launches, the last is reported
             float ms = 0;
             for (int rep = 0; rep < 3; rep++) {
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 hipEventRecord(e0, 0);
-#define DN_LAUNCH(M, T) hipLaunchKernelGGL((k<M, T>), dim3(256), dim3(T), 0, 0, d, st, iters)
+#define DN_LAUNCH(M, T) hipLaunchKernelGGL((k<M, T>), dim3(256), dim3(T), 0, 0, d, st, iters, 1 << 30)
                 if (mode == 0) { if (wps == 1) DN_LAUNCH(0, 256); else if (wps == 2) DN_LAUNCH(0, 512); else DN_LAUNCH(0, 1024); }
                 if (mode == 1) { if (wps == 1) DN_LAUNCH(1, 256); else if (wps == 2) DN_LAUNCH(1, 512); else DN_LAUNCH(1, 1024); }
                 if (mode == 2) { if (wps == 1) DN_LAUNCH(2, 256); else DN_LAUNCH(2, 512); }
@@ -151,6 +153,7 @@ int main()
                 if (mode == 5) { if (wps == 1) DN_LAUNCH(5, 256); else DN_LAUNCH(5, 512); }
                 if (mode == 6) { if (wps == 1) DN_LAUNCH(6, 256); else DN_LAUNCH(6, 512); }
                 if (mode == 7) { if (wps == 1) DN_LAUNCH(7, 256); else DN_LAUNCH(7, 512); }
+                if (mode == 8) { if (wps == 1) DN_LAUNCH(8, 256); else DN_LAUNCH(8, 512); }
                 hipEventRecord(e1, 0);
                 hipDeviceSynchronize();
                 hipEventElapsedTime(&ms, e0, e1);
