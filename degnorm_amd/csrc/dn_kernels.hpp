@@ -377,6 +377,16 @@ __device__ __forceinline__ double rsqrt_newton(double n2)
     return inv;
 }
 
+__device__ __forceinline__ double rcp_newton(double x)
+{
+    // 1 / x for x >= 1: hardware estimate + two Newton steps (error ~1 ulp; an IEEE division costs 15 instructions, and the
+    // residual profile it feeds is compared between bins whose values differ by far more)
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
 template <int KB>
 __device__ __forceinline__ dn_double4 mfma_sym(const double (&h)[KB], const double (&v)[KB])
 {
@@ -890,7 +900,7 @@ __device__ __forceinline__ void col_final(const double (&f)[P], const double (&a
         acc[1 + P + i] += f[i];
         double d = ke - f[i];
         if (!first) d = d < 0.0 ? 0.0 : d;                             // residual of the clamped KE on later trips
-        const double r = d / (f[i] + 1.0);                             // (KE - F) / (F + 1) nmf.py:282
+        const double r = d * rcp_newton(f[i] + 1.0);                   // (KE - F) / (F + 1) nmf.py:282 (denominator >= 1)
         const double r2 = r * r;
         rmax = r2 > rmax ? r2 : rmax;
     }
@@ -1249,12 +1259,20 @@ template <int P> constexpr int rt_regs_used()          // registers a0 .. a(N - 
                ? rt_cols<P, true>() * rt_col_regs<P, true>() : rt_cols<P, false>() * rt_col_regs<P, false>();
 }
 // The caller's contents of the tier's registers, parked in the scratch slot for the duration of one nmf() call:
-// register pair i of lane tid at save[tid * N + i]: lane-major, so that ONE address register and immediate offsets serve
-// all N accesses (register-major would be coalesced but needs N 64-bit addresses, which the compiler keeps alive -- in
-// scratch -- from the save to the restore).
+// register i of lane tid at save[i * NT + tid] (register-major: the 64 lanes of a wave write 256 contiguous bytes; with
+// the save area's base in scalar registers one address register and immediate offsets still serve every access).  The
+// earlier lane-major layout (save[tid * N + i], 16-byte pieces 1 000 bytes apart) measured 0.5 % slower on config 2.
 // Batches of RT_BATCH registers: the loads of a batch are all in flight together (one memory latency per batch, not per
 // register), and the compiler barrier between batches keeps it from gathering every register first.
 constexpr int RT_BATCH = 48;
+#ifndef DN_RT_SAVE_COALESCED
+#define DN_RT_SAVE_COALESCED 1
+#endif
+#if DN_RT_SAVE_COALESCED
+#define DN_RT_SAVE_IDX(r) ((size_t) (r) * NT + threadIdx.x)      // register-major: a wave's 64 lanes write 256 contiguous bytes
+#else
+#define DN_RT_SAVE_IDX(r) ((size_t) threadIdx.x * N + (r))       // lane-major
+#endif
 // `need`: registers a0 .. a(need - 1) are the only ones this call can write (columns beyond the gene's width are never
 // touched), so only whole batches below it are parked.
 template <int N, int NT> __device__ __forceinline__ void rt_save(int *save, int need)
@@ -1266,7 +1284,7 @@ template <int N, int NT> __device__ __forceinline__ void rt_save(int *save, int 
             int v[CNT];
             static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; v[I] = agpr_get1<B + I>(); });
 #pragma unroll
-            for (int i = 0; i < CNT; i++) save[(size_t) threadIdx.x * N + B + i] = v[i];
+            for (int i = 0; i < CNT; i++) save[DN_RT_SAVE_IDX(B + i)] = v[i];
             asm volatile("" ::: "memory");
         }
     });
@@ -1279,7 +1297,7 @@ template <int N, int NT> __device__ __forceinline__ void rt_restore(const int *s
         if (B < need) {
             int v[CNT];
 #pragma unroll
-            for (int i = 0; i < CNT; i++) v[i] = save[(size_t) threadIdx.x * N + B + i];
+            for (int i = 0; i < CNT; i++) v[i] = save[DN_RT_SAVE_IDX(B + i)];
             static_for<0, CNT>([&](auto ic) { constexpr int I = decltype(ic)::value; agpr_put1<B + I>(v[I]); });
             asm volatile("" ::: "memory");
         }
