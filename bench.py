@@ -181,8 +181,10 @@ def parity_check(eng, pick, cfg, p, my_genes, lengths, split, args, rate):
         flips += int(np.sum(np.any(trace_d[:, :7] != trace_o[:, :7], axis=1) | (flags_d != flags_o)))
         checked += len(pick)
     wide = int(np.sum(lengths[pick] > split)) if split > 0 else len(pick)
+    tiny = eng.dev.tiny_length() if (split > 0 and hasattr(eng.dev, 'tiny_length')) else 0
+    n_pair = int(np.sum(lengths[pick] <= tiny)) if tiny > 0 else 0
     return {'max_rel_di': max_rel, 'max_abs_di': max_abs, 'branch_flips': flips, 'genes_checked': len(pick),
-            'gene_iterations_checked': checked, 'outer_iterations': len(eng.scale_hist), 'genes_in_wide_class': wide,
+            'gene_iterations_checked': checked, 'outer_iterations': len(eng.scale_hist), 'genes_in_wide_class': wide, 'genes_in_pair_class': n_pair,
             'tolerance_rel_di': 1e-5, 'ok': bool(flips == 0 and max_rel < 1e-5),
             'what': 'last timed step; oracle (kind: port, pinned to the reference goldens) given each iteration\'s device-side '
                     'scale factors; DI rows unclipped; trace[:7] and flags exact', 'oracle_s': time.time() - t0}
@@ -271,8 +273,10 @@ def main():
         step()
 
     split = eng.dev.split_length()
+    tiny = eng.dev.tiny_length() if split > 0 else 0
     wide = lengths > split if split > 0 else np.ones(len(lengths), dtype=bool)
-    kernel_ms, narrow_ms, all_traces, eng_span = [], [], [], []
+    pair = (lengths <= tiny) & ~wide                                    # class 2: one wavefront per gene, two genes per workgroup
+    kernel_ms, narrow_ms, pair_ms, all_traces, eng_span = [], [], [], [], []
     pick = parity_sample(lengths, args.parity_genes) if (args.parity_genes > 0 and len(lengths) > 0) else None
     eng.history_rows = pick
     init_ms.clear()
@@ -282,6 +286,7 @@ def main():
         step()
         kernel_ms += [c[0] for c in eng.class_ms]
         narrow_ms += [c[1] for c in eng.class_ms]
+        pair_ms += [c[2] for c in eng.class_ms]
         eng_span += list(eng.span_ms)
         all_traces += eng.traces                                       # accounting happens after the clock stops
     sync()
@@ -311,14 +316,15 @@ def main():
             'rccl': rccl,
         }
         if args.config == 'c2':
-            # Two gene classes = two kernels per outer iteration on two streams: class 0 (genes longer than the split length,
-            # 256-thread workgroups, launched first) and class 1 (the others, 128-thread workgroups, two per CU; it takes
-            # over the CUs as class 0 drains, so its launch spans the whole iteration).  The roofline object describes the
-            # kernel with the longer launch; `iteration` puts BOTH kernels' work over the span of the pair.
-            cls_mask = [wide, ~wide]
-            cls_ms = [float(np.mean(kernel_ms)), float(np.mean(narrow_ms))]
-            dom = 0 if cls_ms[0] >= cls_ms[1] else 1
-            oth = 1 - dom
+            # Three gene classes = three kernels per outer iteration on three streams: class 0 (genes longer than the split
+            # length, 256-thread workgroups, launched first), class 1 (128-thread workgroups, two per CU) and class 2 (the
+            # shortest genes, one wavefront per gene, two genes per 128-thread workgroup).  Classes 1 and 2 are launched
+            # right behind class 0 and take over the CUs as it drains, so the one that ends last spans the whole sweep.  The
+            # roofline object describes that kernel (the longest launch) and puts ALL kernels' work over its duration.
+            cls_mask = [wide, ~wide & ~pair, pair]
+            cls_ms = [float(np.mean(kernel_ms)), float(np.mean(narrow_ms)), float(np.mean(pair_ms)) if pair_ms else 0.0]
+            dom = int(np.argmax(cls_ms))
+            others = [c for c in range(3) if c != dom and cls_mask[c].any()]
             mask, avg_ms, name_d = cls_mask[dom], cls_ms[dom], eng.dev.class_kernel_name(dom)
             span_ms = float(np.mean(eng_span)) if eng_span else max(cls_ms)
 
@@ -335,19 +341,20 @@ def main():
             simd_cycles = lambda ms: ms * 1e-3 * 2.4e9 * 256 * 4
             issue_peak = FP64_VECTOR_PEAK_TFLOPS * 4.0 / FP64_ISSUE_CYCLES_1WAVE
             traffic, tinfo = pmc_traffic(args.config, name_d, int(mask.sum())) if (world == 1 and n_genes == cfg['n_genes']) else (None, {'refused': 'not the profiled shard'})
-            traffic_o, tinfo_o = pmc_traffic(args.config, eng.dev.class_kernel_name(oth), int(cls_mask[oth].sum())) if traffic is not None else (None, None)
-            traffic_pair = (traffic + traffic_o) if (traffic is not None and traffic_o is not None) else None
+            traffic_o = {eng.dev.class_kernel_name(c): (pmc_traffic(args.config, eng.dev.class_kernel_name(c), int(cls_mask[c].sum()))[0]
+                                                        if traffic is not None else None) for c in others}
+            traffic_pair = (traffic + sum(traffic_o.values())) if (traffic is not None and all(v is not None for v in traffic_o.values())) else None
             out['roofline'] = {
                 'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tflops / FP64_VECTOR_PEAK_TFLOPS,
-                'what': 'fp64 vector work of ALL genes (both class kernels) / average launch duration of the dominant kernel: the '
-                        'dominant kernel is launched right behind the other one on a second stream and is the last to end, so its '
-                        'launch spans the whole sweep and the other kernel runs INSIDE that window',
+                'what': 'fp64 vector work of ALL genes (every class kernel) / average launch duration of the dominant kernel: the '
+                        'class kernels are launched back to back on their own streams, the dominant one is the last to end, so its '
+                        'launch spans the whole sweep and the other kernels run INSIDE that window',
                 'kernel': name_d, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
-                'genes_in_kernel': int(mask.sum()), 'split_length': split,
-                'concurrent_kernel': {'kernel': eng.dev.class_kernel_name(oth), 'genes': int(cls_mask[oth].sum()),
-                                      'avg_launch_ms': cls_ms[oth], 'sweep_span_ms': span_ms,
-                                      'note': 'the other gene class, own stream, launched first'},
+                'genes_in_kernel': int(mask.sum()), 'split_length': split, 'pair_length': tiny,
+                'concurrent_kernels': [{'kernel': eng.dev.class_kernel_name(c), 'genes': int(cls_mask[c].sum()),
+                                        'avg_launch_ms': cls_ms[c]} for c in others],
+                'sweep_span_ms': span_ms,
                 'dominant_kernel_own_work': {'fp64_tflops': flop_d / (avg_ms * 1e-3) / 1e12,
                                              'frac': flop_d / (avg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                                              'note': 'only the dominant kernel\'s genes over its launch duration (it has the chip to itself '
@@ -360,7 +367,7 @@ def main():
                                      'what': 'fp64 wave-instructions of the passes x 4 cycles / (sweep time x 2.4 GHz x 1024 SIMDs)'},
                 'flop_per_column_iteration': p * p + 9.0 * p,
                 'traffic': traffic_pair, 'traffic_info': tinfo,
-                'traffic_per_kernel': {name_d: traffic, eng.dev.class_kernel_name(oth): traffic_o},
+                'traffic_per_kernel': dict({name_d: traffic}, **traffic_o),
                 'traffic_rate_gbps': (traffic_pair / (avg_ms * 1e-3) / 1e9) if traffic_pair else None,
                 'traffic_frac_of_hbm_peak': (traffic_pair / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_pair else None,
                 'hbm_algorithmic': {'bytes_per_sweep': alg_all, 'rate_gbps': alg_all / (avg_ms * 1e-3) / 1e9, 'hbm_peak_gbps': HBM_PEAK_GBPS,

@@ -76,6 +76,8 @@ def load(build_if_missing=False):
     lib.dn_init_kernel_name.restype = c.c_char_p
     lib.dn_split_length.argtypes = [vp]
     lib.dn_split_length.restype = i32
+    lib.dn_tiny_length.argtypes = [vp]
+    lib.dn_tiny_length.restype = i32
     lib.dn_class_kernel_ms.argtypes = [vp, c.c_int]
     lib.dn_class_kernel_ms.restype = dbl
     lib.dn_class_kernel_name.argtypes = [vp, c.c_int]
@@ -297,6 +299,9 @@ class Device:
 
     def split_length(self):
         return int(self.lib.dn_split_length(self.h))
+
+    def tiny_length(self):
+        return int(self.lib.dn_tiny_length(self.h))
 
     def class_kernel_ms(self, cls):
         return float(self.lib.dn_class_kernel_ms(self.h, int(cls)))

@@ -67,6 +67,11 @@ def build_library(force=False, verbose=False):
             objs.append(o)
             if force or _newer(o, [inst] + hdr):
                 jobs.append([hipcc] + FLAGS + SCHED + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt), '-c', inst, '-o', o])
+    for p in [q for q in P_LIST if 8 <= q <= 12]:      # pair build (one wavefront per gene, two genes per 128-thread workgroup) where
+        o = os.path.join(OBJ, 'dn_inst_p{0}_pair.o'.format(p))      # the register tier exists (csrc/dn_api.hip DN_P_PAIR)
+        objs.append(o)
+        if force or _newer(o, [inst] + hdr):
+            jobs.append([hipcc] + FLAGS + SCHED + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT=64', '-DDN_PAIR=1', '-c', inst, '-o', o])
     gen = os.path.join(CSRC, 'dn_generic.hip')
     for gnt in (256, 64):       # general run-time-p family / one-wavefront-per-gene family (down-sampled regime)
         o_gen = os.path.join(OBJ, 'dn_generic_nt{0}.o'.format(gnt))

@@ -48,6 +48,22 @@ namespace dn {
 DN_FOR_EACH_P(DN_DECL)
 #undef DN_DECL
 
+// Pair build (dn_inst.hip -DDN_PAIR): 128-thread workgroups carrying two genes, one per wavefront, for the shortest genes;
+// compiled where the register tier exists
+#define DN_P_PAIR(X) X(8) X(9) X(10) X(11) X(12)
+#define DN_DECL(P) const KernelSet *kernel_set_p##P##_pair();
+DN_P_PAIR(DN_DECL)
+#undef DN_DECL
+const KernelSet *kernel_set_pair(int p)
+{
+    switch (p) {
+#define DN_CASE(P) case P: return kernel_set_p##P##_pair();
+        DN_P_PAIR(DN_CASE)
+#undef DN_CASE
+        default: return nullptr;
+    }
+}
+
 // 128-thread workgroups (two per CU) for the narrow gene class
 const KernelSet *kernel_set_narrow(int p)
 {
@@ -279,10 +295,15 @@ struct dn_handle_s {
         size_t dyn_lds = 0;
         float last_ms = 0.f;
     };
-    GeneClass cls[2];
-    int32_t split_len = 0;
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev2a = nullptr, ev2b = nullptr, ev_ready = nullptr;
+    static constexpr int NCLS = 3;   // [2]: the shortest genes (length <= tiny_len), one wavefront per gene, two genes per 128-thread
+                                     // workgroup (the pair build): no cross-wave step, the serial phases are paid by ONE SIMD
+    GeneClass cls[NCLS];
+    int32_t split_len = 0, tiny_len = 0;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev2a = nullptr, ev2b = nullptr, ev3a = nullptr, ev3b = nullptr, ev_ready = nullptr;
+    hipStream_t class_stream(int c) const { return c == 0 ? stream : (c == 1 ? stream2 : stream3); }
+    hipEvent_t class_ev_a(int c) const { return c == 0 ? ev0 : (c == 1 ? ev2a : ev3a); }
+    hipEvent_t class_ev_b(int c) const { return c == 0 ? ev1 : (c == 1 ? ev2b : ev3b); }
     int slots = 0;              // class 0 (kept for the run-time-p init kernel)
     int32_t S = 0;
     int64_t slot_bytes = 0;
@@ -340,12 +361,22 @@ int dn_p_supported(int p) { return dn::kernel_set_for(p) != nullptr; }
 
 static int create_streams(dn_handle h)
 {
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // The class kernels of a sweep are queued together on three streams and must start in class order: the wide class needs
+    // whole CUs, and a CU that a narrow or pair workgroup reaches first is lost to it until that (persistent) workgroup has
+    // emptied its queue (seen: the wide kernel then ends LAST, sweep 291 -> 307 ms).  Stream priorities make the dispatcher
+    // place pending wide workgroups first, then narrow ones, then pairs.
+    int prio_least = 0, prio_greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    const int prio_mid = (prio_least + prio_greatest) / 2;
+    HIP_TRY(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_mid));
     HIP_TRY(hipEventCreate(&h->ev2a));
     HIP_TRY(hipEventCreate(&h->ev2b));
+    HIP_TRY(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_least));
+    HIP_TRY(hipEventCreate(&h->ev3a));
+    HIP_TRY(hipEventCreate(&h->ev3b));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&h->ev_i0));
     HIP_TRY(hipEventCreate(&h->ev_i1));
@@ -385,6 +416,9 @@ int dn_destroy(dn_handle h)
     if (h->ev1) (void) hipEventDestroy(h->ev1);
     if (h->ev2a) (void) hipEventDestroy(h->ev2a);
     if (h->ev2b) (void) hipEventDestroy(h->ev2b);
+    if (h->ev3a) (void) hipEventDestroy(h->ev3a);
+    if (h->ev3b) (void) hipEventDestroy(h->ev3b);
+    if (h->stream3) (void) hipStreamDestroy(h->stream3);
     if (h->ev_ready) (void) hipEventDestroy(h->ev_ready);
     if (h->ev_i0) (void) hipEventDestroy(h->ev_i0);
     if (h->ev_i1) (void) hipEventDestroy(h->ev_i1);
@@ -401,7 +435,8 @@ static int size_class(dn_handle h, dn_handle_s::GeneClass &C, int32_t cols)
     if (C.d_ws) { (void) hipFree(C.d_ws); C.d_ws = nullptr; }
     int per_cu = C.ks->blocks_per_cu(0);
     if (per_cu < 1) per_cu = 1;
-    C.slots = (int) std::min<int64_t>(C.n, (int64_t) per_cu * h->n_cus);
+    const int units = std::max(1, C.ks->units);          // genes a workgroup carries at once: a slot and an LDS tile per unit
+    C.slots = (int) std::min<int64_t>(((int64_t) C.n + units - 1) / units * units, (int64_t) per_cu * h->n_cus * units);
     C.S = (cols + 63) & ~63;
     // slot: Fs, Fb (fp32, p x S) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
     C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double)) + (int64_t) C.ks->slot_extra_bytes;
@@ -412,16 +447,16 @@ static int size_class(dn_handle h, dn_handle_s::GeneClass &C, int32_t cols)
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const int64_t budget = (int64_t) (free_b / 3);
         if (C.slot_bytes > budget) return fail(DN_E_INVALID, "a gene is too long for the device scratch (" + std::to_string(C.S) + " columns)");
-        C.slots = (int) std::max<int64_t>(1, std::min<int64_t>(C.slots, budget / C.slot_bytes));
+        C.slots = (int) std::max<int64_t>(units, std::min<int64_t>(C.slots, budget / C.slot_bytes / units * units));
     }
     HIP_TRY(hipMalloc(&C.d_ws, (size_t) C.slot_bytes * (size_t) std::max(C.slots, 1)));
     // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
     const int64_t lds_per_block = (160 * 1024) / per_cu - (int64_t) C.ks->static_lds_bytes - 256;
     const int64_t ps = p + (p & 1);                        // LDS column stride in doubles (16-B aligned)
-    int64_t lcols = lds_per_block > 0 ? lds_per_block / (8 * ps) : 0;
+    int64_t lcols = lds_per_block > 0 ? lds_per_block / units / (8 * ps) : 0;
     lcols = std::min<int64_t>(lcols, C.S) & ~(int64_t) 1;
-    C.lds_cols = (int32_t) lcols;
-    C.dyn_lds = (size_t) lcols * 8 * (size_t) ps;
+    C.lds_cols = (int32_t) lcols;                          // per unit
+    C.dyn_lds = (size_t) units * (size_t) lcols * 8 * (size_t) ps;
     return DN_OK;
 }
 
@@ -499,10 +534,34 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
         }
         if (!narrow) h->split_len = 0;
         if (!env && p >= 25) h->split_len = 0;     // wide cohorts (MFMA Gram): one class measured 3-5 % faster than two
-        std::vector<int32_t> ord[2];
-        for (int32_t g : order) ord[(h->split_len > 0 && h->glen[g] <= h->split_len) ? 1 : 0].push_back(g);   // stays longest-first
+        // Pair class: one wavefront per gene pays reduce + eigen-solve on ONE SIMD instead of two and needs no cross-wave step;
+        // two such genes share a workgroup of the narrow class's shape.  A wavefront keeps its register tier plus its half of
+        // the workgroup's LDS tile on chip (p = 10: 640 + ~480 columns); as for the narrow class the measured optimum of the
+        // boundary is ~1.7 x that capacity (config 2, sweep in ms at 900 / 1 120 / 1 300 / 1 500 / 1 700 / 2 000 / 2 300 /
+        // 2 600 / 3 000: 300.1 / 298.3 / 295.4 / 293.5 / 292.2 / 291.7 / 293.0 / 296.1 / 304.7; without the class 307.7).
+        // DN_TINY_LEN overrides the boundary (0: no such class).
+        const dn::KernelSet *pair = (h->ks->p != 0 && h->split_len > 0) ? dn::kernel_set_pair(p) : nullptr;
+        h->tiny_len = 0;
+        if (pair) {
+            const char *tenv = getenv("DN_TINY_LEN");
+            if (tenv) h->tiny_len = atoi(tenv);
+            else {
+                const int per_cu_t = std::max(1, pair->blocks_per_cu(0));
+                const int64_t lds_t = ((160 * 1024) / per_cu_t - (int64_t) pair->static_lds_bytes - 256) / std::max(1, pair->units);
+                const int64_t lds_cols_t = std::max<int64_t>(0, lds_t / (8 * (int64_t) (p + (p & 1))));
+                h->tiny_len = (int32_t) (1.7 * (double) (pair->reg_tier_cols + lds_cols_t));
+            }
+            h->tiny_len = std::min(h->tiny_len, h->split_len);
+            if (h->tiny_len <= 0) { pair = nullptr; h->tiny_len = 0; }
+        }
+        std::vector<int32_t> ord[dn_handle_s::NCLS];
+        for (int32_t g : order) {                                                                           // stays longest-first
+            const int32_t L = h->glen[g];
+            ord[(h->split_len > 0 && L <= h->split_len) ? ((pair && L <= h->tiny_len) ? 2 : 1) : 0].push_back(g);
+        }
         h->cls[0].ks = h->ks;
         h->cls[1].ks = narrow;
+        h->cls[2].ks = pair;
         {
             // Queue order of a class: longest first, then zigzagged (longest, shortest, 2nd longest, 2nd shortest, ...).
             // Long genes keep most of their state in the spill tier and pull ~60 GB/s per CU through the fabric, short
@@ -513,7 +572,7 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
             // DN_ORDER_MIX=0 restores plain longest-first, bit c selects class c.
             const char *mix = getenv("DN_ORDER_MIX");
             const int mask = mix ? atoi(mix) : 1;
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < dn_handle_s::NCLS; c++) {
                 if (!((mask >> c) & 1) || ord[c].size() < 8) continue;
                 const size_t n0 = ord[c].size();
                 std::vector<int32_t> mixed;
@@ -523,7 +582,7 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
                 ord[c] = mixed;
             }
         }
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < dn_handle_s::NCLS; c++) {
             auto &C = h->cls[c];
             C.n = (int32_t) ord[c].size();
             if (C.n == 0 || !C.ks) { C.n = 0; continue; }
@@ -538,7 +597,7 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
             const int rc = size_class(h, C, cols);
             if (rc != DN_OK) return rc;
         }
-        if (h->cls[0].n == 0 && h->cls[1].n > 0 && h->ks->p == 0) return fail(DN_E_STATE, "internal: empty wide class for the generic kernels");
+        if (h->cls[0].n == 0 && (h->cls[1].n > 0 || h->cls[2].n > 0) && h->ks->p == 0) return fail(DN_E_STATE, "internal: empty wide class for the generic kernels");
         h->slots = h->cls[0].slots; h->S = h->cls[0].S; h->slot_bytes = h->cls[0].slot_bytes; h->d_ws = h->cls[0].d_ws;
     }
     return DN_OK;
@@ -746,7 +805,8 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     // The wide class keeps the zigzag (it is bound by the fabric, see upload).  DN_NARROW_WORK_ORDER=0 disables.
     {
         const char *wo = getenv("DN_NARROW_WORK_ORDER");
-        auto &C = h->cls[1];
+        for (int wc = 1; wc < dn_handle_s::NCLS; wc++) {
+        auto &C = h->cls[wc];
         if (h->have_trace && C.n > 0 && C.ks && !(wo && wo[0] == '0')) {
             const double per_call = 4.0 * (double) (C.ks->nt > 0 ? C.ks->nt : 128);
             std::vector<std::pair<double, int32_t>> key((size_t) C.n);
@@ -759,24 +819,28 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
             for (int32_t k = 0; k < C.n; k++) C.order[k] = key[k].second;
             HIP_TRY(hipMemcpyAsync(C.d_order, C.order.data(), sizeof(int32_t) * (size_t) C.n, hipMemcpyHostToDevice, h->stream));
         }
+        }
     }
     HIP_TRY(hipMemsetAsync(h->d_trace, 0, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, h->stream));
     for (auto &C : h->cls) if (C.n > 0) HIP_TRY(hipMemsetAsync(C.d_counter, 0, sizeof(int32_t) * 4, h->stream));
     HIP_TRY(hipEventRecord(h->ev_ready, h->stream));
-    for (int c = 0; c < 2; c++) {
+    int first_cls = -1;
+    for (int c = 0; c < dn_handle_s::NCLS; c++) {
         auto &C = h->cls[c];
         C.last_ms = 0.f;
         if (C.n == 0) continue;
-        hipStream_t st = c == 0 ? h->stream : h->stream2;
-        if (c == 1) HIP_TRY(hipStreamWaitEvent(st, h->ev_ready, 0));
+        if (first_cls < 0) first_cls = c;
+        hipStream_t st = h->class_stream(c);
+        if (c > 0) HIP_TRY(hipStreamWaitEvent(st, h->ev_ready, 0));
         a.order = C.d_order; a.counter = C.d_counter; a.ws = C.d_ws; a.slot_bytes = C.slot_bytes; a.S = C.S;
         a.lds_cols = C.lds_cols; a.n_genes = C.n;
-        HIP_TRY(hipEventRecord(c == 0 ? h->ev0 : h->ev2a, st));
+        HIP_TRY(hipEventRecord(h->class_ev_a(c), st));
         const int lrc = C.ks->baseline(a, C.slots, C.dyn_lds, st);
         if (lrc != 0) return fail(DN_E_HIP, std::string("k_baseline launch: ") + hipGetErrorString((hipError_t) lrc));
-        HIP_TRY(hipEventRecord(c == 0 ? h->ev1 : h->ev2b, st));
+        HIP_TRY(hipEventRecord(h->class_ev_b(c), st));
     }
-    if (h->cls[1].n > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev2b, 0));     // results are copied on the main stream
+    for (int c = 1; c < dn_handle_s::NCLS; c++)                                   // results are copied on the main stream
+        if (h->cls[c].n > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->class_ev_b(c), 0));
     if (rho) {                          // null: the DI rows stay on the device (dn_outer_partials / dn_outer_apply / dn_fetch_outer)
         HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
@@ -786,16 +850,15 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_trace = (prm->downsample_rate <= 1);          // with down-sampling the active columns are redrawn every iteration
     if (trace) std::memcpy(trace, h->host_trace.data(), sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN);
-    if (h->cls[0].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[0].last_ms, h->ev0, h->ev1));
-    if (h->cls[1].n > 0) HIP_TRY(hipEventElapsedTime(&h->cls[1].last_ms, h->ev2a, h->ev2b));
-    h->last_ms = h->cls[0].n > 0 ? h->cls[0].last_ms : h->cls[1].last_ms;
-    h->last_span_ms = std::max(h->cls[0].last_ms, h->cls[1].last_ms);
-    if (h->cls[0].n > 0 && h->cls[1].n > 0) {
-        float a = 0.f, b = 0.f;                                          // class 1 is launched after class 0: ev0 is the first start
-        HIP_TRY(hipEventElapsedTime(&a, h->ev0, h->ev1));
-        HIP_TRY(hipEventElapsedTime(&b, h->ev0, h->ev2b));
-        h->last_span_ms = std::max(a, b);
+    h->last_span_ms = 0.f;
+    for (int c = 0; c < dn_handle_s::NCLS; c++) {
+        if (h->cls[c].n == 0) continue;
+        HIP_TRY(hipEventElapsedTime(&h->cls[c].last_ms, h->class_ev_a(c), h->class_ev_b(c)));
+        float span = 0.f;                                                // the classes are launched in order: the first start opens the span
+        HIP_TRY(hipEventElapsedTime(&span, h->class_ev_a(first_cls), h->class_ev_b(c)));
+        h->last_span_ms = std::max(h->last_span_ms, span);
     }
+    h->last_ms = first_cls >= 0 ? h->cls[first_cls].last_ms : 0.f;
     h->have_estimate_state = prm->want_estimates != 0;
     return DN_OK;
 }
@@ -962,8 +1025,9 @@ double dn_last_init_ms(dn_handle h) { return h ? (double) h->last_init_ms : 0.0;
 double dn_last_span_ms(dn_handle h) { return h ? (double) h->last_span_ms : 0.0; }
 const char *dn_init_kernel_name(dn_handle h) { return h ? h->init_name : ""; }
 const char *dn_main_kernel_name(dn_handle h) { return (h && h->ks) ? h->ks->baseline_name : ""; }
-double dn_class_kernel_ms(dn_handle h, int cls) { return (h && cls >= 0 && cls < 2) ? (double) h->cls[cls].last_ms : 0.0; }
-const char *dn_class_kernel_name(dn_handle h, int cls) { return (h && cls >= 0 && cls < 2 && h->cls[cls].ks && h->cls[cls].n > 0) ? h->cls[cls].ks->baseline_name : ""; }
+double dn_class_kernel_ms(dn_handle h, int cls) { return (h && cls >= 0 && cls < dn_handle_s::NCLS) ? (double) h->cls[cls].last_ms : 0.0; }
+const char *dn_class_kernel_name(dn_handle h, int cls) { return (h && cls >= 0 && cls < dn_handle_s::NCLS && h->cls[cls].ks && h->cls[cls].n > 0) ? h->cls[cls].ks->baseline_name : ""; }
+int32_t dn_tiny_length(dn_handle h) { return h ? h->tiny_len : 0; }
 int32_t dn_split_length(dn_handle h) { return h ? h->split_len : 0; }
 int dn_synchronize(dn_handle h)
 {

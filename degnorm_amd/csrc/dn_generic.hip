@@ -1066,7 +1066,7 @@ const KernelSet *kernel_set_generic()
         0, gen::NT, gen::launch_baseline, gen::launch_init, gen::launch_est, gen::blocks_per_cu,
         (size_t) 160 * 1024,               // no LDS tier: "static" covers the CU so that lds_cols comes out 0
         "gen::k_baseline_gen",          // as rocprofv3 prints it (dn::gen::k_baseline_gen)
-        0, 0,
+        0, 0, 1,
     };
     return &ks;
 }
@@ -1077,7 +1077,7 @@ const KernelSet *kernel_set_rows()
         0, gen_rows::NT, gen_rows::launch_baseline, gen_rows::launch_init, gen_rows::launch_est, gen_rows::blocks_per_cu,
         (size_t) 160 * 1024,
         "gen_rows::k_baseline_gen",     // dn::gen_rows::k_baseline_gen
-        0, 0,
+        0, 0, 1,
     };
     return &ks;
 }

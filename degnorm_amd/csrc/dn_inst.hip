@@ -38,10 +38,12 @@ static int launch_baseline(const IterArgs &a, int grid, size_t dyn_lds, hipStrea
             configured[dev] = dyn_lds;
         }
     }
-    hipLaunchKernelGGL((k_baseline<DN_P, DN_NT>), dim3(grid), dim3(DN_NT), dyn_lds, s, a);
+    // (pair build: `grid` counts scratch slots = units; a workgroup carries DN_UNITS of them)
+    hipLaunchKernelGGL((k_baseline<DN_P, DN_NT>), dim3((grid + DN_UNITS - 1) / DN_UNITS), dim3(DN_NT * DN_UNITS), dyn_lds, s, a);
     return (int) hipGetLastError();
 }
 
+#ifndef DN_PAIR            // the pair build serves baseline iterations only (the initial pass and the estimates run on the main kernel set)
 static void launch_init(const InitArgs &a, int grid, hipStream_t s)
 {
 #if DN_P <= 16
@@ -56,12 +58,16 @@ static void launch_est(const EstArgs &a, const int32_t *tg, const int32_t *tc, i
     hipLaunchKernelGGL((k_estimates<DN_P>), dim3(n_tiles), dim3(256), 0, s, a, tg, tc);
 }
 
+#endif
+
 static int blocks_per_cu(int which)
 {
     int nb = 0;
     hipError_t e;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline<DN_P, DN_NT>, DN_NT, 0);
-#if DN_P <= 16
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline<DN_P, DN_NT>, DN_NT * DN_UNITS, 0);
+#ifdef DN_PAIR
+    else return 0;
+#elif DN_P <= 16
     else            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd<DN_P, DN_NT>, DN_NT, 0);
 #else
     else return kernel_set_generic()->blocks_per_cu(1);
@@ -70,16 +76,27 @@ static int blocks_per_cu(int which)
 }
 
 #define DN_CAT3(a, b, c, d) DN_CAT(DN_CAT(DN_CAT(a, b), c), d)
+#ifdef DN_PAIR
+const KernelSet *DN_CAT(DN_CAT(kernel_set_p, DN_P), _pair)()
+#else
 const KernelSet *DN_CAT3(kernel_set_p, DN_P, _nt, DN_NT)()
+#endif
 {
     static char name[64];
     snprintf(name, sizeof(name), "k_baseline<%d,%d>", (int) DN_P, (int) DN_NT);
     static const KernelSet ks = {
-        DN_P, DN_NT, launch_baseline, launch_init, launch_est, blocks_per_cu,
-        sizeof(Smem<DN_P, DN_NT>) + sizeof(GeneState<DN_P>),
+        DN_P, DN_NT, launch_baseline,
+#ifdef DN_PAIR
+        nullptr, nullptr,
+#else
+        launch_init, launch_est,
+#endif
+        blocks_per_cu,
+        DN_UNITS * (sizeof(Smem<DN_P, DN_NT>) + sizeof(GeneState<DN_P>)),
         name,
         DN_REG_TIER ? rt_save_bytes<DN_P, DN_NT>() : 0,
         DN_REG_TIER ? rt_cols<DN_P, true>() * DN_NT : 0,
+        DN_UNITS,
     };
     return &ks;
 }

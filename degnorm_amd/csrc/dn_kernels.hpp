@@ -163,8 +163,23 @@ struct Smem {
     int32_t gene;                            // current queue item
 };
 
+// DN_PAIR: a 128-thread workgroup carries TWO genes, one per wavefront ("unit").  Everything the kernels call a workgroup --
+// thread index, barriers, the LDS objects, the scratch slot -- is then a wavefront's: the template runs with NT = 64 and the
+// two units never synchronise with each other (they walk different genes through different control flow).  One wavefront
+// per gene pays reduce + eigen-solve on one SIMD and needs no cross-wave step; pairing two of them in a workgroup of the
+// narrow class's shape (threads, LDS block) keeps the CU's LDS free of the holes that 64-thread workgroups leave between
+// 128-thread ones (third gene class).
+#ifdef DN_PAIR
+#define DN_UNITS 2
+#define DN_TIDX ((int) (threadIdx.x & 63))
+#define DN_UNIT ((int) (threadIdx.x >> 6))
+#else
+#define DN_UNITS 1
+#define DN_TIDX ((int) threadIdx.x)
+#define DN_UNIT 0
+#endif
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ int wave_id() { return DN_UNITS > 1 ? 0 : (int) (threadIdx.x >> 6); }   // wave within the unit
 
 // LDS traffic inside one wave needs no s_barrier: a wave's DS instructions execute in order.  This only stops
 // the compiler from moving LDS accesses across the point.
@@ -173,6 +188,12 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// barrier of the unit: the workgroup's s_barrier, or -- one wavefront per unit -- just the ordering of its LDS traffic
+__device__ __forceinline__ void dn_sync()
+{
+    if constexpr (DN_UNITS > 1) wave_fence(); else __syncthreads();
 }
 
 template <typename T>
@@ -226,7 +247,7 @@ __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm,
     wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1, (SCALE && W == 1) ? sm.gsc + OFF : nullptr);     // ceil(N / 64) rounds
     if constexpr (W > 1) {
         __syncthreads();
-        for (int e = OFF + threadIdx.x; e < OFF + N; e += NT) {         // one trip unless N > NT
+        for (int e = OFF + DN_TIDX; e < OFF + N; e += NT) {         // one trip unless N > NT
             double t = sm.xw[0][e];
 #pragma unroll
             for (int ww = 1; ww < W; ww++) t += sm.xw[ww][e];
@@ -235,7 +256,7 @@ __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm,
             sm.tot[e] = t;
         }
     }
-    __syncthreads();
+    dn_sync();
     // totals are in sm.tot[0..N); no trailing barrier: the next writer of tot / xw sits behind the next
     // call's first barrier
 }
@@ -808,9 +829,11 @@ struct GeneState {
 // The workgroup's LDS objects live at namespace scope so that the out-of-line nmf_call() addresses them with
 // ds_* instructions (a reference parameter would decay to a flat pointer).  One translation unit = one (p, NT).
 #ifdef DN_P
-__shared__ Smem<DN_P, DN_NT> g_sm;
-__shared__ GeneState<DN_P> g_gs;
-extern __shared__ __attribute__((aligned(16))) double g_lam[];      // lambda LDS tier: [p][lds_cols]
+__shared__ Smem<DN_P, DN_NT> g_sm_u[DN_UNITS];
+__shared__ GeneState<DN_P> g_gs_u[DN_UNITS];
+extern __shared__ __attribute__((aligned(16))) double g_lam[];      // lambda LDS tier: [units][lds_cols][p]
+#define g_sm g_sm_u[DN_UNIT]
+#define g_gs g_gs_u[DN_UNIT]
 typedef const float __attribute__((address_space(1))) *gF_cptr;      // compacted raw counts (fp32, exact)
 typedef double __attribute__((address_space(1))) *gdouble_ptr;
 
@@ -995,7 +1018,7 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
     constexpr int TR = Smem<P, NT>::MG_TR, STR = Smem<P, NT>::MG_STR;
     constexpr int NTILE = TR * (TR + 1) / 2;
     Smem<P, NT> &sm = g_sm;
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int tid = DN_TIDX, lane = lane_id(), w = wave_id();
     const int nLe = (n < nL) ? n : nL;
     double *stage = &sm.stage[w * 16 * STR];
     double *uv = &sm.eigv[w * 128], *vv = uv + 64;                     // this wave's copy of u and a work vector
@@ -1110,7 +1133,7 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
                     }
         }
         if constexpr (W > 1) {
-            __syncthreads();
+            dn_sync();
             for (int e = tid; e < NG; e += NT) {
                 double tsum = sm.xw[0][e];
 #pragma unroll
@@ -1118,7 +1141,7 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
                 sm.tot[e] = tsum;
             }
         }
-        __syncthreads();
+        dn_sync();
     };
 
     pass(true, 0);
@@ -1269,9 +1292,9 @@ constexpr int RT_BATCH = 48;
 #define DN_RT_SAVE_COALESCED 1
 #endif
 #if DN_RT_SAVE_COALESCED
-#define DN_RT_SAVE_IDX(r) ((size_t) (r) * NT + threadIdx.x)      // register-major: a wave's 64 lanes write 256 contiguous bytes
+#define DN_RT_SAVE_IDX(r) ((size_t) (r) * NT + DN_TIDX)      // register-major: a wave's 64 lanes write 256 contiguous bytes
 #else
-#define DN_RT_SAVE_IDX(r) ((size_t) threadIdx.x * N + (r))       // lane-major
+#define DN_RT_SAVE_IDX(r) ((size_t) DN_TIDX * N + (r))       // lane-major
 #endif
 // `need`: registers a0 .. a(need - 1) are the only ones this call can write (columns beyond the gene's width are never
 // touched), so only whole batches below it are parked.
@@ -1311,7 +1334,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                                          int n, int S, int nL, int T, int first_i)
 {
     Smem<P, NT> &sm = g_sm;
-    double *lam = g_lam;
+    double *lam = g_lam + (DN_UNITS > 1 ? (size_t) DN_UNIT * (size_t) nL * (P + (P & 1)) : 0);    // this unit's share of the tile
     // every argument is wave-uniform but arrives in vector registers (calling convention): move them to
     // scalar registers so that all row-base arithmetic below is SALU and costs no VGPRs
     gF_cptr Fb = (gF_cptr) uniform_ptr(Fb_);
@@ -1347,7 +1370,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     constexpr int SW = (NG + CH_MAX - 1) / CH_MAX;
     constexpr int CH = (NG + SW - 1) / SW;
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
-    const int tid = threadIdx.x;
+    const int tid = DN_TIDX;
     constexpr bool RAW = DN_RAW_UNITS && P < DN_MG_MIN_P;  // state and Gram partials in raw count units (col_update_raw)
     constexpr int RT = DN_REG_TIER ? rt_cols<P, X16>() : 0;   // columns per lane held in AGPRs (register tier)
     constexpr int CS = rt_col_regs<P, X16>();              // registers per column: the state, and with X16 the packed raw counts
@@ -1356,7 +1379,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     const int kS0 = NR + nL;                               // first column of the spill tier
     if constexpr (P >= DN_MG_MIN_P) {
         const int st = mg_core<P, NT>(Fb, Lg, lam, n, nL, T, u, theta, steps, maxs, noconv);
-        if (st != ST_OK) { if (tid == 0) g_gs.status = st; __syncthreads(); return; }
+        if (st != ST_OK) { if (tid == 0) g_gs.status = st; dn_sync(); return; }
     } else {
     gram_t G[CH];
 
@@ -1397,7 +1420,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         double tr = 0.0;
 #pragma unroll
         for (int i = 0; i < P; i++) tr += sm.tot[i * (i + 1) / 2 + i];
-        if (!(tr > 0.0)) { if (tid == 0) g_gs.status = ST_ARPACK; __syncthreads(); return; }
+        if (!(tr > 0.0)) { if (tid == 0) g_gs.status = ST_ARPACK; dn_sync(); return; }
     }
     Solver<P> solver;
     {
@@ -1692,7 +1715,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         g_gs.stamp[4] += __builtin_amdgcn_s_memtime() - t_fin0; g_gs.stamp[5] += stamp[3];
 #endif
     }
-    __syncthreads();
+    dn_sync();
 }
 
 // Out of line on purpose: the call has its own register allocation (Gram accumulators + one column in flight),
@@ -1721,7 +1744,7 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     } else nmf_body<P, NT, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     rt_restore<NSAVE, NT>(rtsave, need);
 #ifdef DN_STAMP
-    if (threadIdx.x == 0) g_gs.stamp[3] += __builtin_amdgcn_s_memtime() - t_call0;
+    if (DN_TIDX == 0) g_gs.stamp[3] += __builtin_amdgcn_s_memtime() - t_call0;
 #endif
 }
 
@@ -1740,15 +1763,15 @@ template <int P> __device__ __forceinline__ double lds_min(const double *v)
   for (int i = 1; i < P; i++) { const double t = v[i]; m = t < m ? t : m; } return m; }
 
 template <int P, int NT>
-__global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
+__global__ __launch_bounds__(NT * DN_UNITS, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
 {
     constexpr int W = NT / 64;
     Smem<P, NT> &sm = g_sm;
     GeneState<P> &gs = g_gs;
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int tid = DN_TIDX, lane = lane_id(), w = wave_id();
     const int S = A.S;
     const int nL = A.lds_cols;
-    char *slot = A.ws + (size_t) blockIdx.x * A.slot_bytes;
+    char *slot = A.ws + ((size_t) blockIdx.x * DN_UNITS + DN_UNIT) * A.slot_bytes;
     float *Fs = reinterpret_cast<float *>(slot);                      // pristine compacted raw counts  [P][S]
     float *Fb = Fs + (size_t) P * S;                                  // working copy after bin drops   [S][P]
     double *Lg = reinterpret_cast<double *>(Fb + (size_t) P * S);     // x + lambda, spill tier         [S / 64][P][64]
@@ -1774,9 +1797,9 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
 
     for (;;) {
         if (tid == 0) sm.gene = atomicAdd(A.counter, 1);
-        __syncthreads();
+        dn_sync();
         const int q = sm.gene;
-        __syncthreads();
+        dn_sync();
         if (q >= A.n_genes) break;
         const int g = A.order[q];
         const int L = A.glen[g];
@@ -1850,11 +1873,11 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                 }
                 if (pass == 0) {
                     if (lane == 0) sm.cnt[w] = run;
-                    __syncthreads();
+                    dn_sync();
                     n0 = 0;
 #pragma unroll
                     for (int ww = 0; ww < W; ww++) { if (ww < w) base += sm.cnt[ww]; n0 += sm.cnt[ww]; }
-                    __syncthreads();
+                    dn_sync();
                     if (n0 < A.min_hc) break;                                          // nmf.py:232
                 }
             }
@@ -1865,7 +1888,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                     for (int i = 0; i < P; i++) gs.sumF[i] = sumF[i];
                 }
             }
-            __syncthreads();
+            dn_sync();
         }
 
 #ifdef DN_STAMP
@@ -1905,7 +1928,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                                 gs.rho_fb[i] = 1.0 - gs.sumF[i] / (sums[1 + i] + 1.0);
                             }
                         }
-                        __syncthreads();
+                        dn_sync();
                         double med;
                         {
                             double om[P];
@@ -1922,7 +1945,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                         csize = (n0 + A.bins - 1) / A.bins;
                         n_bins = (n0 + csize - 1) / csize;
                         if (tid < n_bins) sm.alive[tid] = tid;
-                        __syncthreads();
+                        dn_sync();
                         first = false;
                     } else {
                         bool zero_row = false;
@@ -1936,7 +1959,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                                 if (!zero_row) gs.rho[i] = 1.0 - sums[1 + P + i] / (sums[1 + i] + 1.0);   // nmf.py:318-321
                             }
                         }
-                        __syncthreads();
+                        dn_sync();
                         if (zero_row) { loop_reason = LOOP_ZERO_ROWSUM; break; }                 // nmf.py:315
                         if ((double) n_bins <= min_bins || (double) n < min_gene_len) { loop_reason = LOOP_MIN_BINS; break; }  // nmf.py:323
                     }
@@ -1959,10 +1982,10 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                         part = wave_sum1(part);
                         if (lane == 0) sm.ss[b] = part / (double) (ke - kb);
                     }
-                    __syncthreads();
+                    dn_sync();
                     double best = -INFINITY; int drop = 0;
                     for (int b = 0; b < n_bins; b++) { const double v = sm.ss[b]; if (v > best) { best = v; drop = b; } }   // nmf.py:291
-                    __syncthreads();
+                    dn_sync();
                     if (best == 0.0) { loop_reason = LOOP_PERFECT; break; }                      // nmf.py:286
                     // drop the bin, renumber (nmf.py:292-302); Fb is rebuilt from the pristine Fs
                     const int kb = drop * csize;
@@ -1974,7 +1997,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                     n_bins--;
                     n -= dlen;
                     n_drops++;
-                    __syncthreads();
+                    dn_sync();
                     // columns in front of the dropped bin keep their place; the others are fetched again from the pristine
                     // copy, four columns per thread in flight
                     for (int k0 = kb + tid; k0 < n; k0 += 4 * NT) {
@@ -1995,7 +2018,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                             }
                         }
                     }
-                    __syncthreads();
+                    dn_sync();
                     if (n < 2) { loop_reason = LOOP_VALUE_ERROR; break; }                        // svds ValueError, nmf.py:306-310
                 }
 
@@ -2024,7 +2047,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                                 const double r = 1.0 - gs.sumF[i] / (K[i] * se[0] + 1.0);         // nmf.py:334-337
                                 rmax = r > rmax ? r : rmax;
                             }
-                            __syncthreads();
+                            dn_sync();
                             if (rmax > 0.9) { fallback = true; exit_code = EXIT_REFINE_FALLBACK; }              // nmf.py:342
                             else {
                                 exit_code = EXIT_REFINED; emode = (n0 < L) ? EM_EXPAND : EM_REFINED;
@@ -2042,7 +2065,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                         }
                         emode = (n0 < L) ? EM_EXPAND : EM_CLAMPED;
                     }
-                    __syncthreads();
+                    dn_sync();
                 }
                 // the re-expansion fix-up runs (and may raise) whenever the estimate is narrower than F  nmf.py:358-362
                 if (status == ST_OK && exit_code >= EXIT_NO_LOOP && n0 < L) {
@@ -2050,7 +2073,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
 #pragma unroll
                     for (int i = 0; i < P; i++) K[i] = gs.K[i];
                     status = fix_k<P>(K);
-                    __syncthreads();
+                    dn_sync();
                     if (tid == 0) {
 #pragma unroll
                         for (int i = 0; i < P; i++) gs.K[i] = K[i];
@@ -2058,7 +2081,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
                 }
             }
         }
-        __syncthreads();
+        dn_sync();
 
         const bool zero_out = (status != ST_OK) || exit_code <= EXIT_MEDIAN;
         if (zero_out) { emode = EM_INPUT; if (status != ST_OK) flag = 0; }
@@ -2088,7 +2111,7 @@ __global__ __launch_bounds__(NT, DN_KERNEL_WAVES) void k_baseline(IterArgs A)
             double *dst = A.svec + A.svoff[g];
             for (int k = tid; k < n0; k += NT) dst[k] = sv[k];
         }
-        __syncthreads();
+        dn_sync();
     }
 }
 
@@ -2101,12 +2124,12 @@ __global__ __launch_bounds__(NT) void k_ratio_svd(InitArgs A)
 {
     constexpr int NG = P * (P + 1) / 2;
     Smem<P, NT> &sm = g_sm;
-    const int tid = threadIdx.x;
+    const int tid = DN_TIDX;
     for (;;) {
         if (tid == 0) sm.gene = atomicAdd(A.counter, 1);
-        __syncthreads();
+        dn_sync();
         const int q = sm.gene;
-        __syncthreads();
+        dn_sync();
         if (q >= A.n_genes) break;
         const int g = A.order[q];
         const int L = A.glen[g];
@@ -2159,7 +2182,7 @@ __global__ __launch_bounds__(NT) void k_ratio_svd(InitArgs A)
             }
             A.status[g] = status;
         }
-        __syncthreads();
+        dn_sync();
     }
 }
 
@@ -2223,7 +2246,10 @@ struct KernelSet {
     size_t static_lds_bytes;          // static LDS of k_baseline
     const char *baseline_name;
     size_t slot_extra_bytes;          // per scratch slot, behind the S-sized arrays (register-tier save area)
-    int reg_tier_cols;                // columns of a gene a workgroup keeps in registers (0: no register tier)
+    int reg_tier_cols;                // columns of a gene a workgroup (a unit) keeps in registers (0: no register tier)
+    int units;                        // genes a workgroup carries at once (2: the pair build, one gene per wavefront; else 1).
+                                      // `nt` threads, the LDS tile and a scratch slot belong to ONE unit; `static_lds_bytes`,
+                                      // blocks_per_cu() and the dynamic LDS of a launch to the workgroup
 };
 
 const KernelSet *kernel_set_for(int p);   // dn_api.hip

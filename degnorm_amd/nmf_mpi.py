@@ -283,7 +283,7 @@ class ShardedNMFOA(object):
         else:
             rho, flags, trace = np.zeros((0, p)), np.zeros(0, dtype=bool), np.zeros((0, _lib.TRACE_LEN), dtype=np.int32)
             self.kernel_ms.append(0.0)
-            self.class_ms.append((0.0, 0.0))
+            self.class_ms.append((0.0, 0.0, 0.0))
         self.traces.append(trace)
         self.scale_hist.append(np.copy(self.scale_factors))
         if self.history_rows is not None:                             # raw device outputs of a few genes (bench.py's parity check)
@@ -312,7 +312,7 @@ class ShardedNMFOA(object):
     def _record_kernel_times(self):
         self.kernel_ms.append(self.dev.last_kernel_ms())
         if hasattr(self.dev, 'class_kernel_ms'):
-            self.class_ms.append((self.dev.class_kernel_ms(0), self.dev.class_kernel_ms(1)))
+            self.class_ms.append(tuple(self.dev.class_kernel_ms(c) for c in range(3)))
             self.span_ms.append(self.dev.last_span_ms())
 
     def _reduce_and_update(self, i, partials):

@@ -151,9 +151,12 @@ const char *dn_main_kernel_name(dn_handle h);
 /* The same for the most recent dn_ratio_svd_sums (the initial pass over the whole transcripts).       */
 double dn_last_init_ms(dn_handle h);
 const char *dn_init_kernel_name(dn_handle h);
-/* Genes are run in two classes: class 0 = genes longer than dn_split_length() (256-thread workgroups, one per CU),
- * class 1 = the others (128-thread workgroups, two per CU); one kernel launch per class and outer iteration. */
+/* Genes are run in up to three classes: class 0 = genes longer than dn_split_length() (256-thread workgroups, one per CU),
+ * class 1 = the others (128-thread workgroups, two per CU), class 2 = genes of at most dn_tiny_length() bases (one wavefront
+ * per gene, two genes per 128-thread workgroup; 0 when the class does not exist for this sample count); one kernel launch
+ * per non-empty class and outer iteration. */
 int32_t dn_split_length(dn_handle h);
+int32_t dn_tiny_length(dn_handle h);
 double dn_class_kernel_ms(dn_handle h, int cls);
 /* First launch to last end of the class kernels of the most recent dn_baseline_iteration (they overlap).          */
 double dn_last_span_ms(dn_handle h);

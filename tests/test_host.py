@@ -137,7 +137,7 @@ def test_save_results_files(tmp_path):
         assert list(pickle.load(f)) == ['g1']
 
 
-@pytest.mark.parametrize('p,nt', [(10, 256), (10, 128), (12, 128)])
+@pytest.mark.parametrize('p,nt', [(10, 256), (10, 128), (12, 128), (10, -64)])          # -64: the pair build (two genes per workgroup)
 def test_register_tier_registers_are_private(tmp_path, p, nt):
     """
     The register tier (csrc/dn_kernels.hpp) keeps x + lambda in AGPRs through inline v_accvgpr moves with literal register
@@ -151,7 +151,10 @@ def test_register_tier_registers_are_private(tmp_path, p, nt):
     from degnorm_amd import build
     src = os.path.join(ROOT, 'degnorm_amd', 'csrc', 'dn_inst.hip')
     out = str(tmp_path / 'k.s')
-    cmd = [build._hipcc()] + build.FLAGS + build.SCHED + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt), '-S', '--cuda-device-only', src, '-o', out]
+    pair = nt < 0
+    nt = abs(nt)
+    cmd = [build._hipcc()] + build.FLAGS + build.SCHED + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt)] + (['-DDN_PAIR=1'] if pair else []) + \
+          ['-S', '--cuda-device-only', src, '-o', out]
     subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     fn, inasm = None, False
     compiler_agpr = {}          # function -> instructions outside inline asm that name an AGPR
@@ -204,5 +207,9 @@ def test_register_tier_registers_are_private(tmp_path, p, nt):
     restores = [r for r in runs if len(r) >= n_tier and regs_of(r[-n_tier:]) == set(range(n_tier))]
     assert len(restores) >= len(re.findall(r's_setpc_b64 s\[30:31\]', body)) >= 1     # returns (other s_setpc are long branches)
     assert all('v_accvgpr_write_b32' in b for b in blocks[-n_tier:]) and regs_of(blocks[-n_tier:]) == set(range(n_tier))
+    if pair:
+        # the two wavefronts of a pair workgroup walk different genes: a workgroup barrier anywhere in the kernel would deadlock
+        kb = text[text.index('_ZN2dn8nmf_call'):text.index('.amdhsa_kernel _ZN2dn10k_baseline')]
+        assert 's_barrier' not in kb
     kern = text[text.index('.amdhsa_kernel _ZN2dn10k_baseline'):]
     assert re.search(r'\.amdhsa_next_free_vgpr 512\b', kern[:4000]) and re.search(r'\.amdhsa_accum_offset 256\b', kern[:4000])   # (3)

@@ -71,12 +71,16 @@ def main():
         'source_sha256': hashes['source_sha256'],
         'lib_sha256': hashes['lib_sha256'],
         'split_length': bench['roofline'].get('split_length'),
+        'pair_length': bench['roofline'].get('pair_length'),
         'kernels': {},
     }
     names = [(bench['roofline'].get('kernel'), bench['roofline'].get('genes_in_kernel'))]
     for key in ('second_kernel', 'concurrent_kernel', 'iteration_kernel'):
         k = bench['roofline'].get(key)
         if k and k.get('kernel'):
+            names.append((k['kernel'], k.get('genes')))
+    for k in bench['roofline'].get('concurrent_kernels') or []:
+        if k.get('kernel'):
             names.append((k['kernel'], k.get('genes')))
     for name, genes in names:
         if not name:
