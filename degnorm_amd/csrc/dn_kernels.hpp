@@ -8,7 +8,8 @@
 //   k_estimates<P>     the `estimate` output of baseline_selection             nmf.py:327-365
 //
 // Mapping: one workgroup of NT threads (NT / 64 wavefronts) owns one gene at a time and walks the whole
-// baseline-selection state machine for it; workgroups are persistent and pull genes from a work queue.  Columns (base
+// baseline-selection state machine for it; workgroups are persistent and pull genes from a work queue.  (The DN_PAIR build
+// gives every wavefront of a 128-thread workgroup its own gene: "workgroup" below then reads "wavefront".)  Columns (base
 // positions) are spread over lanes, the p samples of a column live in one lane's registers, so every global / LDS
 // access is lane-contiguous.
 //
