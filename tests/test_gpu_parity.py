@@ -477,6 +477,50 @@ def test_sample_counts_and_edge_shapes_vs_oracle(device, oracle, p):
     np.testing.assert_allclose(rho1[0], oracle.baseline_batch(covs[:1], scale, oracle.make_params(nmf_iter=12))[0][0], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize('p', [8, 10, 12])
+def test_pair_class_agrees_with_narrow_class_and_oracle(oracle, monkeypatch, p):
+    """
+    The pair class (one wavefront per gene, two genes per 128-thread workgroup: the DN_PAIR build, csrc/dn_kernels.hpp) against
+    the same genes on the narrow class (DN_TINY_LEN=0) and against the oracle: genes below and above a wavefront's on-chip
+    capacity (register tier only / + LDS tier / + spill tier), an odd number of them (the last workgroup has one idle
+    unit), one with a count beyond 16 bits (the variant that re-reads its counts), estimates included.
+    """
+    from degnorm_amd import _lib
+    covs = [synth.synth_gene(21, g, p, lo, hi)[0] for g, (lo, hi) in enumerate(
+        [(200, 500)] * 6 + [(600, 640)] * 3 + [(700, 1100)] * 6 + [(1200, 1800)] * 5 + [(2500, 2600)] * 1)]
+    big = np.array(covs[2], dtype=float)
+    big[0, :7] = 70000.0                                                   # not packable into 16 bits
+    covs.append(big)
+    assert len(covs) % 2 == 0
+    covs = covs[:-1] + [covs[-1]] + [synth.synth_gene(22, 0, p, 300, 300)[0]]      # odd count in the pair class
+    scale = np.linspace(0.85, 1.25, p)
+    T = 14
+    out = {}
+    for tiny in ('0', None):
+        if tiny is None:
+            monkeypatch.delenv('DN_TINY_LEN', raising=False)
+        else:
+            monkeypatch.setenv('DN_TINY_LEN', tiny)
+        dev = _lib.Device(0)
+        try:
+            dev.upload(covs)
+            rho, flags, trace = dev.baseline_iteration(scale, nmf_iter=T, want_estimates=True)
+            out[tiny] = (rho, flags, trace, dev.fetch_estimates(), dev.tiny_length(), dev.class_kernel_name(2))
+        finally:
+            dev.close()
+    assert out['0'][4] == 0 and out['0'][5] == ''
+    assert out[None][4] > 1200 and out[None][5] == 'k_baseline<{0},64>'.format(p)
+    rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, scale, oracle.make_params(nmf_iter=T), want_estimates=True)
+    for key in ('0', None):
+        rho, flags, trace, est = out[key][:4]
+        np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
+        np.testing.assert_array_equal(flags, flags_o)
+        np.testing.assert_allclose(rho, rho_o, rtol=RTOL, atol=ATOL)
+        for a, b in zip(est, est_o):
+            np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8)
+    assert (out[None][2][:, 1] > 1).sum() >= 5                            # the drop-bin loop ran on several genes
+
+
 def test_api_lifecycle_and_seeded_downsampling(tmp_path):
     """Re-use of one model / device with different shapes, seeded systematic sampling, estimate shapes, result files."""
     from collections import OrderedDict
