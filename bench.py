@@ -194,8 +194,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', default='c2', choices=['c2', 'c4'])
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=2)    # the first step after the first-ever one still carries ~18 ms of one-time host cost
     ap.add_argument('--genes', type=int, default=0, help='total genes (default: the configuration\'s: 20000 / 50000)')
     ap.add_argument('--iters', type=int, default=5, help='outer DegNorm iterations per step')
     ap.add_argument('--nmf-iter', type=int, default=100)
