@@ -758,6 +758,22 @@ __device__ __forceinline__ void gram_add_range(T (&G)[CNT], const double (&a)[P]
         }
 }
 
+// G = a a^T on the packed entries [LO, LO + CNT): the first column of a pass STARTS the accumulators
+template <int P, int LO, int CNT, typename T>
+__device__ __forceinline__ void gram_set_range(T (&G)[CNT], const double (&a)[P])
+{
+    T b[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) b[i] = (T) a[i];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            const int idx = i * (i + 1) / 2 + j;
+            if (idx >= LO && idx < LO + CNT) G[idx - LO] = b[i] * b[j];
+        }
+}
+
 template <int P, typename T>
 __device__ __forceinline__ void gram_add(T (&G)[P * (P + 1) / 2], const double (&a)[P])
 {
@@ -1181,6 +1197,12 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #ifndef DN_RT_MAX_P
 #define DN_RT_MAX_P 12           // above it the Gram accumulators alone need more than 256 registers
 #endif
+#ifndef DN_ONCHIP_BODY
+#define DN_ONCHIP_BODY 1         // a fourth nmf() body for genes that fill the register tier AND fit on chip (no spill tier in it)
+#endif
+#ifndef DN_GRAM_FIRST
+#define DN_GRAM_FIRST 1          // ... whose first tier column starts the Gram accumulators
+#endif
 #ifndef DN_RT_STRAIGHT
 #define DN_RT_STRAIGHT 1         // genes that fill the register tier walk it as straight-line code (no per-column exec mask)
 #endif
@@ -1330,7 +1352,10 @@ template <int N, int NT> __device__ __forceinline__ void rt_restore(const int *s
 template <int P, int NT> constexpr size_t rt_save_bytes() { return (size_t) rt_regs_used<P>() * 4 * NT; }
 
 // FULL: the gene fills the register tier (n >= RT * NT): every lane owns all RT columns and the tier is walked as straight-line code
-template <int P, int NT, bool X16, bool FULL = false>
+// ONCHIP (with FULL): the gene also fits the register + LDS tiers (n <= RT * NT + lds_cols): the body carries no spill tier,
+// which is where the register pressure of the pass peaks -- the registers that frees let the first tier column start the Gram
+// accumulators (no zeroing, two-source multiplies) without a spill
+template <int P, int NT, bool X16, bool FULL = false, bool ONCHIP = false>
 __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *rs_, double *sv_,
                                          int n, int S, int nL, int T, int first_i)
 {
@@ -1462,10 +1487,13 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #ifdef DN_STAMP
     stamp[3] += __builtin_amdgcn_s_memtime() - t_cold0;
 #endif
+    constexpr bool G0 = DN_GRAM_FIRST && FULL && ONCHIP && SW == 1 && !RAW;
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
+        if constexpr (!G0) {
 #pragma unroll
-        for (int i = 0; i < CH; i++) G[i] = 0.0;
+            for (int i = 0; i < CH; i++) G[i] = 0.0;
+        }
         { DN_T0();
         // The columns are walked forwards on even passes and backwards on odd ones (spill tier first, then the LDS tier):
         // what the previous pass touched last -- the end of the spill state and of the counts -- is still in the XCD's
@@ -1507,7 +1535,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                     if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
                     DN_PH1(2); }
                     { DN_PH0(3);
-                    gram_add_range<P, 0, CH>(G, a);
+                    if constexpr (G0 && R == 0) gram_set_range<P, 0, CH>(G, a); else gram_add_range<P, 0, CH>(G, a);
                     DN_PH1(3); }
                     { DN_PH0(4);
                     rt_write<P, CS * R>(a);
@@ -1572,6 +1600,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         // spill tier: x + lambda of the columns that do not fit in LDS lives in the slot (L2 / Infinity Cache).
         // Here the loads are far away, and prefetching the next column's counts and state does pay (1.15x).
         auto spill_tier = [&]() {
+            if constexpr (ONCHIP) return;
             const int first = kS0 + tid;
             const int cnt = first < n ? (n - first + NT - 1) / NT : 0;
             const int step = dir * NT;
@@ -1608,7 +1637,8 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #else
 #define DN_TIER(id, call) call
 #endif
-        if (dir > 0) { DN_TIER(1, reg_tier()); DN_TIER(2, lds_tier()); DN_TIER(3, spill_tier()); }
+        if constexpr (G0) { DN_TIER(1, reg_tier()); DN_TIER(2, lds_tier()); }       // the register tier touches no memory: its place is free
+        else if (dir > 0) { DN_TIER(1, reg_tier()); DN_TIER(2, lds_tier()); DN_TIER(3, spill_tier()); }
         else { DN_TIER(3, spill_tier()); DN_TIER(2, lds_tier()); DN_TIER(1, reg_tier()); }
 #if !(defined(DN_STAMP) && defined(DN_EXP_TIER))
         DN_T1(0);
@@ -1740,7 +1770,11 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
         // a third body for the genes that fill the register tier: a second variant of the tier INSIDE one body costs registers
         // the pass does not have (the allocator starts spilling Gram accumulators in the loop)
         constexpr bool X = DN_REG_TIER != 0;
-        if (DN_RT_STRAIGHT && X && n_u >= rt_cols<P, X>() * NT) nmf_body<P, NT, X, X && (DN_RT_STRAIGHT != 0)>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+        constexpr bool ST = X && (DN_RT_STRAIGHT != 0);
+        const int nL_u = __builtin_amdgcn_readfirstlane(nL);
+        if (ST && DN_ONCHIP_BODY && n_u >= rt_cols<P, X>() * NT && n_u <= rt_cols<P, X>() * NT + nL_u)
+            nmf_body<P, NT, X, ST, ST && (DN_ONCHIP_BODY != 0)>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+        else if (ST && n_u >= rt_cols<P, X>() * NT) nmf_body<P, NT, X, ST>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
         else nmf_body<P, NT, X, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     } else nmf_body<P, NT, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     rt_restore<NSAVE, NT>(rtsave, need);
