@@ -317,7 +317,8 @@ struct dn_handle_s {
     int32_t ds_hint = 1;          // take-every rate the caller intends to use (dn_set_downsample_hint); 1 = none
     int32_t max_steps = dn::EIG_MAX_STEPS_DEFAULT;   // step cap of one eigen-solve (dn_set_solver_step_cap)
     // per-gene counters of the previous dn_baseline_iteration: the narrow class orders its queue by the work they predict
-    std::vector<int32_t> host_trace;
+    int32_t *host_trace = nullptr;        // pinned (hipHostMalloc): the per-gene counters come back every iteration (n x TRACE_LEN)
+    size_t host_trace_len = 0;
     bool have_trace = false;
 
 };
@@ -329,6 +330,7 @@ static void free_device(dn_handle h)
                     h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col, h->d_rowmax, h->d_x16, h->d_rhoc, h->d_xw, h->d_xadj,
                     h->d_part, h->d_pvec, h->d_ran};
     for (void *q : ptrs) if (q && q != (void *) h->cls[0].d_ws) (void) hipFree(q);
+    if (h->host_trace) { (void) hipHostFree(h->host_trace); h->host_trace = nullptr; h->host_trace_len = 0; }
     for (auto &c : h->cls) {
         if (c.d_order) (void) hipFree(c.d_order);
         if (c.d_counter) (void) hipFree(c.d_counter);
@@ -845,11 +847,15 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
         HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
     }
-    h->host_trace.resize((size_t) h->n * dn::TRACE_LEN);
-    HIP_TRY(hipMemcpyAsync(h->host_trace.data(), h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
+    if (h->host_trace_len < (size_t) h->n * dn::TRACE_LEN) {
+        if (h->host_trace) { (void) hipHostFree(h->host_trace); h->host_trace = nullptr; h->host_trace_len = 0; }
+        HIP_TRY(hipHostMalloc((void **) &h->host_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipHostMallocDefault));
+        h->host_trace_len = (size_t) h->n * dn::TRACE_LEN;
+    }
+    HIP_TRY(hipMemcpyAsync(h->host_trace, h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_trace = (prm->downsample_rate <= 1);          // with down-sampling the active columns are redrawn every iteration
-    if (trace) std::memcpy(trace, h->host_trace.data(), sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN);
+    if (trace) std::memcpy(trace, h->host_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN);
     h->last_span_ms = 0.f;
     for (int c = 0; c < dn_handle_s::NCLS; c++) {
         if (h->cls[c].n == 0) continue;
