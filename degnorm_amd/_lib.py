@@ -59,6 +59,9 @@ def load(build_if_missing=False):
     lib.dn_baseline_iteration.argtypes = [vp, P(dbl), P(Params), P(i64), P(dbl), P(i32), P(i32)]
     lib.dn_fetch_estimates.argtypes = [vp, P(dbl)]
     lib.dn_outer_begin.argtypes = [vp, P(dbl), i32]
+    lib.dn_init_begin.argtypes = [vp, P(dbl)]
+    lib.dn_init_partials.argtypes = [vp, P(dbl)]
+    lib.dn_outer_begin_scaled.argtypes = [vp, P(dbl), i32]
     lib.dn_outer_partials.argtypes = [vp, P(dbl)]
     lib.dn_outer_apply.argtypes = [vp, P(dbl), P(dbl), i32]
     lib.dn_fetch_outer.argtypes = [vp, P(dbl), P(dbl), P(dbl), P(c.c_uint8)]
@@ -180,13 +183,35 @@ class Device:
         return self
 
     # -- compute -----------------------------------------------------------------------------------
-    def ratio_svd_sums(self):
+    def ratio_svd_sums(self, fetch=True):
+        """fetch=False leaves the two n x p sums on the device (init_partials reduces them there); returns (None, None, None)."""
+        if not fetch:
+            _check(self.lib.dn_ratio_svd_sums(self.h, None, None, None))
+            return None, None, None
         est = np.zeros((self.n, self.p))
         cov = np.zeros((self.n, self.p))
         status = np.zeros(self.n, dtype=np.int32)
         _check(self.lib.dn_ratio_svd_sums(self.h, _p(est, ctypes.c_double), _p(cov, ctypes.c_double),
                                           _p(status, ctypes.c_int32)))
         return est, cov, status
+
+    def init_begin(self, reads):
+        x = np.ascontiguousarray(reads, dtype=np.float64)
+        if x.shape != (self.n, self.p):
+            raise ValueError('reads must be n x p')
+        _check(self.lib.dn_init_begin(self.h, _p(x, ctypes.c_double)))
+
+    def init_partials(self):
+        out = np.zeros(3 * self.p + 3)
+        _check(self.lib.dn_init_partials(self.h, _p(out, ctypes.c_double)))
+        return out
+
+    def outer_begin_scaled(self, norm, degnorm_iter):
+        nm = np.ascontiguousarray(norm, dtype=np.float64)
+        if nm.shape != (self.p,):
+            raise ValueError('norm must have one entry per sample')
+        self._n_iter = int(degnorm_iter)
+        _check(self.lib.dn_outer_begin_scaled(self.h, _p(nm, ctypes.c_double), int(degnorm_iter)))
 
     def baseline_iteration(self, scale, nmf_iter=100, bins=20, min_high_coverage=50, downsample_rate=1,
                            skip_baseline_selection=False, want_estimates=False, ds_start=None, want_trace=True, fetch=True):

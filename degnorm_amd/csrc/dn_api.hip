@@ -181,6 +181,49 @@ __global__ __launch_bounds__(256) void k_outer_partials(const double *__restrict
     }
 }
 
+// The initial normalisation on the device (nmf.py:524-531): rho0 = 1 - cov_sums / (est_sums + 1) per gene, `low` =
+// (max_i rho0 < 0.1), per-sample sums of the read counts over the low genes and over all genes, the number of low genes and
+// of genes whose initial SVD failed.  Same block-partial layout as k_outer_partials (A = low sums, B = all sums, W unused).
+__global__ __launch_bounds__(256) void k_init_partials(const double *__restrict__ est, const double *__restrict__ cov,
+                                                       const int32_t *__restrict__ status, const double *__restrict__ x,
+                                                       double *__restrict__ part, int n, int p)
+{
+    __shared__ double sm[4][3][64];
+    __shared__ double cnt[4][3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    double a = 0.0, b = 0.0, nl = 0.0, nb = 0.0;
+    for (int g = blockIdx.x * 4 + w; g < n; g += nw) {
+        double r = -INFINITY, xv = 0.0;
+        if (lane < p) {
+            r = 1.0 - cov[(size_t) g * p + lane] / (est[(size_t) g * p + lane] + 1.0);       // nmf.py:526
+            xv = x[(size_t) g * p + lane];
+        }
+        const bool low = wave_max_d(r) < 0.1;                             // nmf.py:529
+        a += low ? xv : 0.0;
+        b += xv;
+        if (lane == 0) { nl += low ? 1.0 : 0.0; nb += status[g] != 0 ? 1.0 : 0.0; }
+    }
+    sm[w][0][lane] = a; sm[w][1][lane] = b; sm[w][2][lane] = 0.0;
+    if (lane == 0) { cnt[w][0] = nl; cnt[w][1] = nb; cnt[w][2] = 0.0; }
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int k = threadIdx.x >> 6, i = threadIdx.x & 63;
+        part[(size_t) blockIdx.x * OUT_STRIDE + 64 * k + i] = ((sm[0][k][i] + sm[1][k][i]) + sm[2][k][i]) + sm[3][k][i];
+    } else if (threadIdx.x < 195) {
+        const int k = threadIdx.x - 192;
+        part[(size_t) blockIdx.x * OUT_STRIDE + 192 + k] = ((cnt[0][k] + cnt[1][k]) + cnt[2][k]) + cnt[3][k];
+    }
+}
+
+// x_weighted = x / norm (nmf.py:533)
+__global__ __launch_bounds__(256) void k_scale_reads(const double *__restrict__ x, const double *__restrict__ norm,
+                                                     double *__restrict__ xw, long long np, int p)
+{
+    for (long long i = (long long) blockIdx.x * 256 + threadIdx.x; i < np; i += (long long) gridDim.x * 256)
+        xw[i] = x[i] / norm[i % p];
+}
+
 __global__ __launch_bounds__(256) void k_outer_reduce(const double *__restrict__ part, double *__restrict__ out, int nblocks, int p)
 {
     const int t = threadIdx.x;
@@ -268,6 +311,7 @@ struct dn_handle_s {
     int32_t *d_x16 = nullptr;         // n: 1 when every count of the gene is a whole number <= 65535 (packable into 16 bits)
     // outer-update state (dn_outer_begin): clipped / corrected DI, x_weighted, x_adj, ran_baseline_selection, partial sums
     double  *d_rhoc = nullptr, *d_xw = nullptr, *d_xadj = nullptr, *d_part = nullptr, *d_pvec = nullptr;
+    double  *d_x = nullptr;           // the read counts (n x p), resident for the device-side initial normalisation (dn_init_begin)
     uint8_t *d_ran = nullptr;
     int32_t  n_iter = 0;
     double  *d_est_sums = nullptr, *d_cov_sums = nullptr;
@@ -328,7 +372,7 @@ static void free_device(dn_handle h)
     void *ptrs[] = {h->d_cov, h->d_goff, h->d_glen, h->d_order, h->d_counter, h->d_ds, h->d_ws, h->d_rho, h->d_flags,
                     h->d_trace, h->d_kfin, h->d_emode, h->d_svec, h->d_svoff, h->d_est_sums, h->d_cov_sums,
                     h->d_status, h->d_est, h->d_tile_gene, h->d_tile_col, h->d_rowmax, h->d_x16, h->d_rhoc, h->d_xw, h->d_xadj,
-                    h->d_part, h->d_pvec, h->d_ran};
+                    h->d_part, h->d_pvec, h->d_ran, h->d_x};
     for (void *q : ptrs) if (q && q != (void *) h->cls[0].d_ws) (void) hipFree(q);
     if (h->host_trace) { (void) hipHostFree(h->host_trace); h->host_trace = nullptr; h->host_trace_len = 0; }
     for (auto &c : h->cls) {
@@ -343,6 +387,7 @@ static void free_device(dn_handle h)
     h->d_cov_sums = nullptr; h->d_status = nullptr; h->d_est = nullptr; h->d_tile_gene = nullptr; h->d_tile_col = nullptr;
     h->d_rowmax = nullptr; h->d_x16 = nullptr;
     h->d_rhoc = nullptr; h->d_xw = nullptr; h->d_xadj = nullptr; h->d_part = nullptr; h->d_pvec = nullptr; h->d_ran = nullptr;
+    h->d_x = nullptr;
     h->n_iter = 0;
     h->have_estimate_state = false;
 }
@@ -719,7 +764,7 @@ int dn_upload_ragged(dn_handle h, int64_t n_genes, int32_t p, const void *const 
 int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *status)
 {
     if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_ratio_svd_sums: nothing uploaded");
-    if (!est_sums || !cov_sums) return fail(DN_E_INVALID, "dn_ratio_svd_sums: null output");
+    if ((est_sums == nullptr) != (cov_sums == nullptr)) return fail(DN_E_INVALID, "dn_ratio_svd_sums: the two sums are fetched together or not at all");
     HIP_TRY(hipSetDevice(h->device));
     dn::InitArgs a;
     a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.order = h->d_order; a.counter = h->d_counter;
@@ -734,11 +779,11 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_i1, h->stream));
     const size_t np = (size_t) h->n * h->p;
-    HIP_TRY(hipMemcpyAsync(est_sums, h->d_est_sums, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(cov_sums, h->d_cov_sums, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
-    std::vector<int32_t> st_local;
-    if (!status) { st_local.resize(h->n); status = st_local.data(); }
-    HIP_TRY(hipMemcpyAsync(status, h->d_status, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
+    if (est_sums) {                     // null: the sums stay on the device (dn_init_partials reduces them there)
+        HIP_TRY(hipMemcpyAsync(est_sums, h->d_est_sums, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(cov_sums, h->d_cov_sums, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (status) HIP_TRY(hipMemcpyAsync(status, h->d_status, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipEventElapsedTime(&h->last_init_ms, h->ev_i0, h->ev_i1));
     if (h->ks->p >= 2 && h->ks->p <= 16) snprintf(h->init_name, sizeof(h->init_name), "k_ratio_svd<%d,%d>", h->ks->p, h->ks->nt);
@@ -869,24 +914,78 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
     return DN_OK;
 }
 
+static int outer_alloc(dn_handle h, int32_t degnorm_iter)
+{
+    const size_t np = (size_t) h->n * h->p;
+    if (!h->d_rhoc) {
+        HIP_TRY(hipMalloc(&h->d_rhoc, sizeof(double) * np));
+        HIP_TRY(hipMalloc(&h->d_xw, sizeof(double) * np));
+        HIP_TRY(hipMalloc(&h->d_xadj, sizeof(double) * np));
+    }
+    if (!h->d_part) {
+        HIP_TRY(hipMalloc(&h->d_part, sizeof(double) * (size_t) OUT_BLOCKS * OUT_STRIDE));
+        HIP_TRY(hipMalloc(&h->d_pvec, sizeof(double) * (3 * dn::P_MAX + 4 + 2 * dn::P_MAX)));
+    }
+    if (degnorm_iter > 0 && h->n_iter != degnorm_iter) {
+        if (h->d_ran) { (void) hipFree(h->d_ran); h->d_ran = nullptr; }
+        HIP_TRY(hipMalloc(&h->d_ran, (size_t) h->n * degnorm_iter));
+        h->n_iter = degnorm_iter;
+    }
+    return DN_OK;
+}
+
+int dn_init_begin(dn_handle h, const double *reads)
+{
+    if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_init_begin: nothing uploaded");
+    if (!reads) return fail(DN_E_INVALID, "dn_init_begin: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t np = (size_t) h->n * h->p;
+    if (!h->d_x) HIP_TRY(hipMalloc(&h->d_x, sizeof(double) * np));
+    HIP_TRY(hipMemcpyAsync(h->d_x, reads, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
+int dn_init_partials(dn_handle h, double *partials)
+{
+    if (!h || !h->d_x) return fail(DN_E_STATE, "dn_init_partials: dn_init_begin has not been called");
+    if (!partials) return fail(DN_E_INVALID, "dn_init_partials: null output");
+    HIP_TRY(hipSetDevice(h->device));
+    { const int rc = outer_alloc(h, 0); if (rc != DN_OK) return rc; }
+    const int blocks = (int) std::min<int64_t>(OUT_BLOCKS, (h->n + 3) / 4);
+    hipLaunchKernelGGL(k_init_partials, dim3(blocks), dim3(256), 0, h->stream, h->d_est_sums, h->d_cov_sums, h->d_status, h->d_x, h->d_part,
+                       (int) h->n, (int) h->p);
+    hipLaunchKernelGGL(k_outer_reduce, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_pvec, blocks, (int) h->p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(partials, h->d_pvec, sizeof(double) * (size_t) (3 * h->p + 3), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
+int dn_outer_begin_scaled(dn_handle h, const double *norm, int32_t degnorm_iter)
+{
+    if (!h || !h->d_x) return fail(DN_E_STATE, "dn_outer_begin_scaled: dn_init_begin has not been called");
+    if (!norm || degnorm_iter < 1) return fail(DN_E_INVALID, "dn_outer_begin_scaled: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    { const int rc = outer_alloc(h, degnorm_iter); if (rc != DN_OK) return rc; }
+    const size_t np = (size_t) h->n * h->p;
+    double *d_norm = h->d_pvec + (3 * dn::P_MAX + 4) + dn::P_MAX;
+    HIP_TRY(hipMemsetAsync(h->d_ran, 0, (size_t) h->n * degnorm_iter, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_norm, norm, sizeof(double) * (size_t) h->p, hipMemcpyHostToDevice, h->stream));
+    const int blocks = (int) std::min<size_t>(2048, (np + 255) / 256);
+    hipLaunchKernelGGL(k_scale_reads, dim3(blocks), dim3(256), 0, h->stream, h->d_x, d_norm, h->d_xw, (long long) np, (int) h->p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
 int dn_outer_begin(dn_handle h, const double *x_weighted, int32_t degnorm_iter)
 {
     if (!h || !h->d_cov) return fail(DN_E_STATE, "dn_outer_begin: nothing uploaded");
     if (!x_weighted || degnorm_iter < 1) return fail(DN_E_INVALID, "dn_outer_begin: bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const size_t np = (size_t) h->n * h->p;
-    if (!h->d_rhoc) {
-        HIP_TRY(hipMalloc(&h->d_rhoc, sizeof(double) * np));
-        HIP_TRY(hipMalloc(&h->d_xw, sizeof(double) * np));
-        HIP_TRY(hipMalloc(&h->d_xadj, sizeof(double) * np));
-        HIP_TRY(hipMalloc(&h->d_part, sizeof(double) * (size_t) OUT_BLOCKS * OUT_STRIDE));
-        HIP_TRY(hipMalloc(&h->d_pvec, sizeof(double) * (3 * dn::P_MAX + 4 + 2 * dn::P_MAX)));
-    }
-    if (h->n_iter != degnorm_iter) {
-        if (h->d_ran) { (void) hipFree(h->d_ran); h->d_ran = nullptr; }
-        HIP_TRY(hipMalloc(&h->d_ran, (size_t) h->n * degnorm_iter));
-        h->n_iter = degnorm_iter;
-    }
+    { const int rc = outer_alloc(h, degnorm_iter); if (rc != DN_OK) return rc; }
     HIP_TRY(hipMemsetAsync(h->d_ran, 0, (size_t) h->n * degnorm_iter, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_xw, x_weighted, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

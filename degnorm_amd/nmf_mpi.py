@@ -220,25 +220,40 @@ class ShardedNMFOA(object):
         if self.global_ids.shape != (self.n_local,):
             raise ValueError('global_ids must name every local gene')
         self.n_total = int(n_total) if n_total is not None else self.n_local
+        self._reads_on_device = False
+        if self.n_local > 0 and self.device_outer and hasattr(self.dev, 'init_begin'):
+            self.dev.init_begin(self.x)              # the read counts live next to the coverage: the initial normalisation runs there
+            self._reads_on_device = True
 
     # -- algorithm --------------------------------------------------------------------------------
     def initialize(self):
         """ratio-SVD DI scores and the initial normalisation factors (nmf.py:521-535, nmf_mpi.py:681-718)."""
         p = self.p
-        if self.n_local > 0:
-            est_sums, cov_sums, status = self.dev.ratio_svd_sums()
+        # With the device-side update the two n x p sums of the initial pass never leave the GPU either: it reduces rho0, the
+        # low genes and their read counts itself (dn_init_partials) and the host sees 2p + 2 numbers.
+        on_device = self.device_outer and self.n_local > 0 and getattr(self, '_reads_on_device', False) and hasattr(self.dev, 'outer_begin')
+        if on_device:
+            self.dev.ratio_svd_sums(fetch=False)
+            pv = self.dev.init_partials()
+            n_bad_local, part = float(pv[3 * p + 1]), np.concatenate([pv[:p], pv[p:2 * p], [pv[3 * p]]])
+            self.rho = None                                            # rho0 stays on the device
         else:
-            est_sums, cov_sums, status = np.zeros((0, p)), np.zeros((0, p)), np.zeros(0, dtype=np.int32)
-        n_bad = _allreduce(self.comm, [float(np.sum(status != 0))])[0]
+            if self.n_local > 0:
+                est_sums, cov_sums, status = self.dev.ratio_svd_sums()
+            else:
+                est_sums, cov_sums, status = np.zeros((0, p)), np.zeros((0, p)), np.zeros(0, dtype=np.int32)
+            n_bad_local = float(np.sum(status != 0))
+        n_bad = _allreduce(self.comm, [n_bad_local])[0]
         if n_bad > 0:                                                 # every rank raises together
             raise ValueError('rank-1 SVD failed on {0} gene(s) during initialisation (all-zero coverage?)'.format(int(n_bad)))
-        self.rho = 1 - (cov_sums / (est_sums + 1))
-        low = self.rho.max(axis=1) < 0.1 if self.n_local > 0 else np.zeros(0, dtype=bool)
-        part = np.concatenate([self.x[low].sum(axis=0), self.x.sum(axis=0), [float(low.sum())]])
+        if not on_device:
+            self.rho = 1 - (cov_sums / (est_sums + 1))
+            low = self.rho.max(axis=1) < 0.1 if self.n_local > 0 else np.zeros(0, dtype=bool)
+            part = np.concatenate([self.x[low].sum(axis=0), self.x.sum(axis=0), [float(low.sum())]])
         tot = _allreduce(self.comm, part)
         count_sums = tot[:p] if tot[2 * p] > 0 else tot[p:2 * p]
         self.norm_factors = count_sums / np.median(count_sums)
-        self.x_weighted = self.x / self.norm_factors
+        self.x_weighted = None if on_device else self.x / self.norm_factors      # on the device: formed there, fetched by fetch_state()
         self.scale_factors = np.copy(self.norm_factors)
         self.ran_baseline_selection = np.zeros((self.n_local, self.degnorm_iter), dtype=bool)
         self._rng = np.random.RandomState(self.random_state)
@@ -247,7 +262,10 @@ class ShardedNMFOA(object):
         # weighted and adjusted counts and the flags then stay in HBM and come back once, in fetch_state().
         self._device_outer = self.device_outer and self.n_local > 0 and hasattr(self.dev, 'outer_begin')
         if self._device_outer:
-            self.dev.outer_begin(self.x_weighted, max(1, self.degnorm_iter))
+            if on_device:
+                self.dev.outer_begin_scaled(self.norm_factors, max(1, self.degnorm_iter))
+            else:
+                self.dev.outer_begin(self.x_weighted, max(1, self.degnorm_iter))
         self._state_on_device = False
         self.kernel_ms, self.traces, self.class_ms, self.span_ms = [], [], [], []
         self.n_failed = []

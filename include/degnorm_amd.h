@@ -115,6 +115,18 @@ int  dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *pr
  *   dn_fetch_outer     final rho / x_adj / x_weighted (n x p each) and ran_baseline_selection (n x degnorm_iter bytes); any may be NULL
  *   dn_fetch_rows      raw (unclipped) DI rows and flags of a few genes of the last dn_baseline_iteration (diagnostics)          */
 int  dn_outer_begin(dn_handle h, const double *x_weighted, int32_t degnorm_iter);
+/* The initial normalisation on the device -------------------------------------------------------------
+ * Replaces: rho0 = 1 - cov_sums / (est_sums + 1), the `low` genes (rho0.max() < 0.1) and the per-sample sums of their read
+ * counts, nmf.py:524-531 (nmf_mpi.py:681-718 on rank 0) -- O(n p) host arithmetic on two n x p matrices that
+ * dn_ratio_svd_sums would otherwise have to copy back -- and x_weighted = x / norm (:533).
+ *   dn_init_begin          reads (n x p float64 read counts) -> device, once per upload
+ *   dn_ratio_svd_sums      may then be called with est_sums = cov_sums = NULL (the sums stay in HBM)
+ *   dn_init_partials       partials[0:p] = sum over the low genes of x, [p:2p] = sum over all genes of x, [3p] = #low genes,
+ *                          [3p+1] = #genes whose initial SVD failed ([2p:3p], [3p+2] unused); fixed order, for the all-reduce
+ *   dn_outer_begin_scaled  dn_outer_begin with x_weighted = reads / norm formed on the device                        */
+int  dn_init_begin(dn_handle h, const double *reads);
+int  dn_init_partials(dn_handle h, double *partials);
+int  dn_outer_begin_scaled(dn_handle h, const double *norm, int32_t degnorm_iter);
 int  dn_outer_partials(dn_handle h, double *partials);
 int  dn_outer_apply(dn_handle h, const double *avg_di, const double *norm, int32_t iter);
 int  dn_fetch_outer(dn_handle h, double *rho, double *x_adj, double *x_weighted, uint8_t *ran);
