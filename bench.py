@@ -2,33 +2,44 @@
 bench.py -- DegNorm NMF-OA hot path on MI355X.
 
     python bench.py [--config c2|c4] [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this process is only a LAUNCHER: before touching torch or the GPU it
+starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+as a child process (one rank per GPU over RCCL), relays rank 0's single JSON line to its own stdout and exits non-zero if
+any rank fails (the reference's counterpart: `mpiexec -n R degnorm_mpi`, __main_mpi__.py:29-43, nmf_mpi.py:555-629).
+Started under torchrun (WORLD_SIZE set) it is one rank.
 
 --config c2 (default; BASELINE.json's metric, configs[1] / configs[2] when sharded): 20 000 synthetic genes x 10
 samples, L ~ U[200, 5000], 5 DegNorm iterations, nmf_iter = 100.
 --config c4 (configs[3]): 50 000 genes x 50 samples, L ~ U[501, 5000], take-every 500, 5 iterations.
 
-One "step" = one complete DegNorm run over the resident genes: the ratio-SVD initialisation pass plus `--iters` (5)
-outer iterations, each = the baseline-selection kernels over every gene of the rank's shard, the D2H of the DI rows /
-flags / traces and the per-sample all-reduce (RCCL over xGMI under torchrun, also at N = 1).  Coverage is generated and
-uploaded to HBM before the timed region (estimates are not fetched).  The genes are sharded across the N ranks by
-length (utils.partition_by_length), so scaling is strong; `value` = total genes / max-over-ranks wall time.
+One "step" = one complete DegNorm run over the resident genes: the ratio-SVD initialisation pass, `--iters` (5) outer
+iterations -- each = the baseline-selection kernels over every gene of the rank's shard, the device-side outer update and the
+per-sample all-reduce (RCCL, also at N = 1) -- and the D2H of the final DI scores / adjusted counts / flags (fetch_state).
+Coverage is generated and uploaded to HBM before the timed region; estimates are not fetched (reported in `end_to_end`).
+The genes are sharded across the N ranks by predicted cost (utils.partition_by_cost), so scaling is strong; `value` =
+total genes / max-over-ranks wall time.
 
 Rank 0 prints ONE JSON line with the driver contract fields plus
   roofline      the dominant kernel against the resource that binds it (c2: fp64 vector issue, with the measured
                 one-wave issue ceiling as a second peak and SURVEY 8(d)'s algorithmic bytes/s as a named secondary
-                figure; c4: HBM bytes of the initial pass), `traffic` from the committed rocprofv3 PMC passes of THIS
-                source tree (refused when the sources differ from the profiled ones),
-  parity        after the clock stops: the oracle re-runs a sample of genes with the scale factors each timed outer
-                iteration actually used, and the device's DI rows / branch traces of the LAST timed step are compared,
-  cpu_baseline  the oracle on this box's host cores on a bounded sample.
+                figure; c4: HBM bytes of the initial pass + the latency bound of the iteration kernel), `traffic` from the
+                committed rocprofv3 PMC passes of THIS source tree (refused when the sources differ from the profiled ones),
+  parity        after the clock stops: (i) the oracle re-runs a sample of genes with the scale factors each timed outer
+                iteration actually used (kernels alone), (ii) `chain`: the whole run -- initial pass, 5 iterations, device-side
+                outer update -- on the CPU-baseline sample against the oracle's own run, flipped genes counted and measured,
+                (iii) `tie_sensitive`: genes with a column exactly on the 0.1 x max threshold of get_high_coverage_idx,
+  end_to_end    GeneNMFOA.fit(cov_dict, reads) on the full float64 coverage dict: pack + H2D, run, estimates, D2H,
+  cpu_baseline  the oracle on this box's host cores (all cores, and one thread) on a bounded sample,
+  also          (default run only) config 4 measured in the same process after config 2.
 """
 import argparse
 import glob
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,9 +55,66 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2
 # registers only) at 4.22 cycles per instruction against the 4 of the peak above (two waves per SIMD: 3.95); a stream of
 # nothing but dependent-free fp64 FMAs issues slower (5.75, 4.4 with four waves).  The kernel runs one wave per SIMD.
 FP64_ISSUE_CYCLES_1WAVE = 4.22
-ROUND = 'round2'
+ROUND = 'round3'
+REFERENCE_PY_GENES_PER_S_PER_THREAD = 0.18    # the reference itself (n_jobs = 1) on config-2-like genes, 5 iterations
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher (no torch, no GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, launcher=None):
+    """
+    Start the N rank processes as FRESH children (never exec: the GPU box forbids replacing a process) and relay rank 0's
+    JSON line.  `launcher` replaces the `python -m torch.distributed.run ...` prefix (tests use a stub); the environment
+    variable DN_BENCH_LAUNCHER (a JSON list) does the same for a parent started as a script.  Returns the exit code.
+    """
+    if launcher is None and os.environ.get('DN_BENCH_LAUNCHER'):
+        launcher = json.loads(os.environ['DN_BENCH_LAUNCHER'])
+    if launcher is None:
+        launcher = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+                    '--master-addr', '127.0.0.1', '--master-port', str(_free_port())]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')            # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(1, n))))
+    env['DN_BENCH_PARENT'] = str(os.getpid())
+    cmd = list(launcher) + [os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, universal_newlines=True, env=env)
+    line = None
+    for raw in proc.stdout:
+        text = raw.strip()
+        is_line = False
+        if text.startswith('{'):
+            try:
+                is_line = 'metric' in json.loads(text)
+            except ValueError:
+                pass
+        if is_line:
+            line = text
+        else:
+            sys.stderr.write(raw)                                 # whatever else the ranks print goes to stderr
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write('bench.py: the rank launcher exited with code {0}\n'.format(rc))
+        return rc if 0 < rc < 256 else 1
+    if line is None:
+        sys.stderr.write('bench.py: the ranks finished without printing a result line\n')
+        return 3
+    print(line)
+    sys.stdout.flush()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# accounting helpers
+# ---------------------------------------------------------------------------------------------------------------------
 def source_hash():
     """sha256 over the kernel sources and the build recipe: identifies the binary build() makes from this tree."""
     h = hashlib.sha256()
@@ -70,7 +138,7 @@ def algorithmic_bytes(trace, lengths, p, nmf_iter, mask=None):
     SURVEY.md 8(d): per gene and outer iteration, fp32 storage, one fused pass per inner NMF-OA iteration that
     reads x and lambda and writes lambda:  bytes_g = 4 p [ L_g + sum_k n_{g,k} (3T + 3) + L_g ],
     with sum_k n_{g,k} (active columns summed over the gene's nmf() calls) taken from the device counters.
-    `mask` selects the genes one kernel processes (the two gene classes run in separate launches).
+    `mask` selects the genes one kernel processes (the gene classes run in separate launches).
     """
     sum_cols = trace[:, 2].astype(np.float64)
     per_gene = 4.0 * p * (2.0 * lengths + sum_cols * (3.0 * nmf_iter + 3.0))
@@ -79,7 +147,7 @@ def algorithmic_bytes(trace, lengths, p, nmf_iter, mask=None):
 
 def pmc_traffic(config, kernel_name, genes_in_kernel):
     """
-    Fabric-side bytes per launch of the dominant kernel from the PMC counters.  bench.py cannot collect PMCs itself: the
+    Fabric-side bytes per launch of a kernel from the PMC counters.  bench.py cannot collect PMCs itself: the
     figure comes from committed rocprofv3 passes of THIS command (tools/profile_round.sh -> profiles/<round>/
     pmc_traffic_<config>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
     calibration).  It is reported only when the profile was taken from the same kernel sources (source_hash), kernel
@@ -127,8 +195,16 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(cfg, name, p, nmf_iter, iters, rate, n_sample):
-    """The CPU oracle (oracle/, parity-pinned port of the reference) timed on this box's host cores."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline + whole-chain parity (post-clock)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg, name, p, nmf_iter, iters, rate, n_sample, n_single):
+    """
+    The CPU oracle (oracle/, parity-pinned port of the reference) timed on this box's host cores: all cores on `n_sample`
+    genes and ONE thread on the first `n_single` of them (the reference-equivalent mode: the reference's own multiprocessing
+    is thread-based and GIL-bound).  Returns (the cpu_baseline object, the oracle's run on the sample -- reused by
+    the chain parity check --, the sample's coverage matrices and read counts).
+    """
     from oracle import oracle as orc
     from degnorm_amd import synth
     orc.build()
@@ -138,24 +214,102 @@ def cpu_baseline(cfg, name, p, nmf_iter, iters, rate, n_sample):
     ds = None
     if rate > 1:
         ds = np.random.RandomState(123).randint(0, rate, size=(iters, n_sample)).astype(np.int64)
+    kw = dict(degnorm_iter=iters, nmf_iter=nmf_iter, downsample_rate=rate, min_high_coverage=2 if rate > 1 else 50)
+    hist = {}
     t0 = time.time()
-    orc.run(covs, reads, degnorm_iter=iters, nmf_iter=nmf_iter, downsample_rate=rate, min_high_coverage=2 if rate > 1 else 50,
-            ds_starts=ds, n_threads=cores)
+    ref = orc.run(covs, reads, ds_starts=ds, n_threads=cores, history=hist, **kw)
     dt = time.time() - t0
-    return {'value': n_sample / dt, 'unit': 'genes/sec', 'cores': cores, 'kind': 'port',
-            'sample': 'first {0} genes of the {1} generator, full run ({2} outer iterations, nmf_iter {3}{4}), '
-                      'oracle/nmfoa_oracle.c with OpenMP over genes, {5:.1f} s wall'
-                      .format(n_sample, name, iters, nmf_iter, ', take-every {0}'.format(rate) if rate > 1 else '', dt)}
+    ref['history'] = hist
+    ref['ds_starts'] = ds
+    single = None
+    if n_single > 0:
+        k = min(n_single, n_sample)
+        t1 = time.time()
+        orc.run(covs[:k], reads[:k], ds_starts=None if ds is None else ds[:, :k], n_threads=1, **kw)
+        d1 = time.time() - t1
+        single = {'value': k / d1, 'unit': 'genes/sec', 'cores': 1, 'sample': 'first {0} genes, {1:.1f} s wall'.format(k, d1)}
+    tail = ', take-every {0}'.format(rate) if rate > 1 else ''
+    out = {'value': n_sample / dt, 'unit': 'genes/sec', 'cores': cores, 'kind': 'port',
+           'sample': 'first {0} genes of the {1} generator, full run ({2} outer iterations, nmf_iter {3}{4}), '
+                     'oracle/nmfoa_oracle.c with OpenMP over genes, {5:.1f} s wall.  Beside it: `single_thread` = the same port on '
+                     'one thread; the reference\'s own Python (scipy ARPACK, n_jobs = 1) measured in the build container on '
+                     'config-2-like genes = {6} genes/s per thread (BASELINE.md section 2, not re-run here)'
+                     .format(n_sample, name, iters, nmf_iter, tail, dt, REFERENCE_PY_GENES_PER_S_PER_THREAD),
+           'single_thread': single,
+           'reference_python_genes_per_s_per_thread': REFERENCE_PY_GENES_PER_S_PER_THREAD if name == 'c2' else None}
+    return out, ref, covs, reads
+
+
+def chain_parity(ref, covs, reads, nmf_iter, iters, rate, device):
+    """
+    The whole chain on the device against the oracle's own run of the same genes: initial ratio-SVD pass and normalisation,
+    every outer iteration's kernels, dn_outer_partials -> all-reduce -> dn_outer_apply, fetch_state -- through
+    GeneNMFOA.fit().  Unlike `parity_check` nothing is handed over between the two runs: each follows its OWN scale factors.
+    A gene is `flipped` when its branch trace differs in any iteration (a 0.1 x max threshold tie decided by the last bit of a
+    scale factor); flipped genes are counted and their DI distance reported, NOT excluded silently.
+    """
+    from collections import OrderedDict
+    from degnorm_amd.nmf import GeneNMFOA
+    n = len(covs)
+    m = GeneNMFOA(degnorm_iter=iters, nmf_iter=nmf_iter, downsample_rate=rate, device=device)
+    if ref.get('ds_starts') is not None:
+        m.downsample_offsets = ref['ds_starts']
+    t0 = time.time()
+    m.fit(OrderedDict(('g%06d' % k, c) for k, c in enumerate(covs)), reads)
+    dt = time.time() - t0
+    flipped = np.zeros(n, dtype=bool)
+    for i in range(iters):
+        flipped |= np.any(m.traces[i][:, :7] != ref['history']['trace'][i][:, :7], axis=1)
+    flipped |= np.any(m.ran_baseline_selection != ref['ran_baseline_selection'], axis=1)
+    ok = ~flipped
+    rel = np.abs(m.rho - ref['rho']) / np.maximum(np.abs(ref['rho']), 1e-6)
+    rel_adj = np.abs(m.x_adj - ref['x_adj']) / np.maximum(np.abs(ref['x_adj']), 1e-300)
+    out = {'genes': n, 'outer_iterations': iters,
+           'max_rel_di_final': float(rel[ok].max()) if ok.any() else None,
+           'max_rel_adjusted_counts': float(rel_adj[ok].max()) if ok.any() else None,
+           'max_rel_scale_factors': float(np.max(np.abs(m.scale_factors - ref['scale_factors']) / ref['scale_factors'])),
+           'flipped_genes': int(flipped.sum()),
+           'flipped_max_abs_di': float(np.abs(m.rho - ref['rho'])[flipped].max()) if flipped.any() else 0.0,
+           'flipped_max_rel_adjusted_counts': float(rel_adj[flipped].max()) if flipped.any() else 0.0,
+           'device_s': dt,
+           'what': 'GeneNMFOA.fit() on the cpu_baseline sample vs the oracle\'s own full run (each side follows its own scale '
+                   'factors through all outer iterations, device-side outer update included); flipped = branch trace or flags differ'}
+    out['ok'] = bool(out['max_rel_scale_factors'] < 1e-5 and (out['max_rel_di_final'] or 0.0) < 1e-5)
+    return out
+
+
+def tie_sensitive_genes(packed, lengths, p, scale):
+    """
+    Genes with a column sitting exactly on the threshold of get_high_coverage_idx (nmf.py:66-76: max_i F_ij > 0.1 max F,
+    F = x / s): the comparison of such a column is decided by the last bit of the quotients, so ANY change of the scale
+    factors in the 16th digit (another BLAS, another summation order) may move the gene onto another branch -- in the
+    reference as well.  Counted at the given scale factors, within 4 ulp of the threshold.
+    """
+    inv = (1.0 / np.asarray(scale, dtype=np.float64))[:, None]
+    n_sens, n_cols, o = 0, 0, 0
+    for L in lengths:
+        L = int(L)
+        F = packed[o:o + p * L].reshape(p, L).astype(np.float64) * inv
+        o += p * L
+        cm = F.max(axis=0)
+        thr = 0.1 * cm.max()
+        near = np.abs(cm - thr) <= 8.9e-16 * thr
+        k = int(near.sum())
+        n_cols += k
+        n_sens += k > 0
+    return {'genes': int(n_sens), 'columns': int(n_cols), 'of_genes': int(len(lengths)),
+            'what': 'genes with >= 1 column whose scaled maximum is within 4 ulp of 0.1 x max F at the final scale factors: '
+                    'their branch is decided by round-off of the scale factors (nmf.py:76), in the reference too'}
 
 
 def parity_sample(lengths, k):
-    """Genes at evenly spaced length quantiles: both gene classes and the whole work queue."""
+    """Genes at evenly spaced length quantiles: every gene class and the whole work queue."""
     n = len(lengths)
     by_len = np.argsort(lengths, kind='stable')
     return np.unique(by_len[np.linspace(0, n - 1, min(k, n)).round().astype(int)])
 
 
-def parity_check(eng, pick, cfg, p, my_genes, lengths, split, args, rate):
+def parity_check(eng, pick, cfg, p, my_genes, lengths, split, nmf_iter, rate):
     """
     Post-clock value check of the LAST timed step.  For every outer iteration of that step the oracle processes a sample
     of this rank's genes (chosen before the clock started; the engine kept their raw device rows) with the scale factors
@@ -167,7 +321,7 @@ def parity_check(eng, pick, cfg, p, my_genes, lengths, split, args, rate):
     from degnorm_amd import synth
     orc.build()
     covs = [synth.synth_gene(cfg['seed'], my_genes[j], p, cfg['l_min'], cfg['l_max'])[0] for j in pick]
-    prm = orc.make_params(args.nmf_iter, 20, 2 if rate > 1 else 50, rate, False)
+    prm = orc.make_params(nmf_iter, 20, 2 if rate > 1 else 50, rate, False)
     cores = host_cores()
     max_rel, max_abs, flips, checked = 0.0, 0.0, 0, 0
     t0 = time.time()
@@ -190,60 +344,70 @@ def parity_check(eng, pick, cfg, p, my_genes, lengths, split, args, rate):
                     'scale factors; DI rows unclipped; trace[:7] and flags exact', 'oracle_s': time.time() - t0}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--config', default='c2', choices=['c2', 'c4'])
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=2)    # the first step after the first-ever one still carries ~18 ms of one-time host cost
-    ap.add_argument('--genes', type=int, default=0, help='total genes (default: the configuration\'s: 20000 / 50000)')
-    ap.add_argument('--iters', type=int, default=5, help='outer DegNorm iterations per step')
-    ap.add_argument('--nmf-iter', type=int, default=100)
-    ap.add_argument('--cpu-sample', type=int, default=-1, help='genes in the CPU-baseline sample (0 = skip; default 768 / 2048)')
-    ap.add_argument('--parity-genes', type=int, default=160, help='genes in the post-clock parity sample (0 = skip)')
-    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                    help='collective backend under torchrun: nccl = RCCL (the measured path); gloo only to rehearse N > 1 on ONE GPU '
-                         '(every rank on device 0; the line is then marked "rehearsal")')
-    args = ap.parse_args()
+def end_to_end(packed, lengths, p, reads, iters, nmf_iter, rate, device, reps=2):
+    """
+    SURVEY 8(d)(i): the call the degnorm CLI makes (__main__.py:264-270) -- GeneNMFOA.fit(cov_dict, reads) on the float64
+    coverage dict of the WHOLE configuration: host packing (threads) + H2D, the run, the estimates of the last iteration
+    (rebuild + D2H + list of views) and the D2H of rho / x_adj / x_weighted / flags.  `genes_per_s` excludes the
+    estimates (as SURVEY defines the metric), `genes_per_s_with_estimates` includes them.
+    """
+    from collections import OrderedDict
+    from degnorm_amd.nmf import GeneNMFOA
+    t0 = time.time()
+    cov_dat, o = OrderedDict(), 0
+    for g, L in enumerate(lengths):
+        L = int(L)
+        cov_dat['gene_%06d' % g] = packed[o:o + p * L].reshape(p, L).astype(np.float64)      # what the CLI hands over (reads.py:714)
+        o += p * L
+    t_dict = time.time() - t0
+    runs = []
+    for _ in range(reps):
+        m = GeneNMFOA(degnorm_iter=iters, nmf_iter=nmf_iter, downsample_rate=rate, device=device)
+        t1 = time.time()
+        est = m.fit(cov_dat, reads)
+        total = time.time() - t1
+        tm = dict(m.timings)
+        tm['total_s'] = total
+        tm['other_host_s'] = total - sum(m.timings.values())
+        runs.append(tm)
+        n_est = len(est)
+        del est
+        m._dev.close()
+    best = min(runs, key=lambda r: r['total_s'])
+    n = len(lengths)
+    return {'pack_s': best['pack_upload_s'], 'upload_s': None, 'pack_upload_s': best['pack_upload_s'], 'run_s': best['run_s'],
+            'fetch_state_s': best['fetch_state_s'], 'estimates_s': best['estimates_s'], 'other_host_s': best['other_host_s'],
+            'total_s': best['total_s'],
+            'genes_per_s': n / (best['total_s'] - best['estimates_s']), 'genes_per_s_with_estimates': n / best['total_s'],
+            'estimates_returned': n_est, 'input_bytes_float64': int(8 * p * int(np.sum(lengths))), 'calls': runs,
+            'dict_build_s_untimed': t_dict,
+            'what': 'GeneNMFOA.fit(OrderedDict of float64 p x L matrices, reads) on the whole configuration, best of {0} calls (all '
+                    'listed under `calls`; the first one also pays one-time allocations); pack_upload_s = float64 -> float32 packing '
+                    'on the host threads into a pinned staging buffer + H2D + row maxima (one C call, dn_upload_ragged; `pack_s` '
+                    'repeats it, `upload_s` is not separable)'.format(reps)}
 
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
-        args.gpus = world
 
+# ---------------------------------------------------------------------------------------------------------------------
+# one configuration on this rank
+# ---------------------------------------------------------------------------------------------------------------------
+def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2e):
+    """Generate, upload, time `steps` steps; rank 0 returns the result object (other ranks None)."""
     import torch
     from degnorm_amd import synth
-    from degnorm_amd.nmf_mpi import ShardedNMFOA, TorchComm, LocalComm
-    from degnorm_amd.utils import partition_by_length
+    from degnorm_amd.nmf_mpi import ShardedNMFOA
+    from degnorm_amd.utils import partition_by_cost
 
-    rehearsal = args.backend == 'gloo'
-    if rehearsal:
-        local_rank = 0                                                  # all ranks share the one GPU
-    torch.cuda.set_device(local_rank)
-    comm = LocalComm()
-    distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ     # under torchrun use RCCL even at N = 1
-    rccl = None
-    if distributed:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group('gloo')
-            comm = TorchComm(device='cpu')
-        else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-            comm = TorchComm(device='cuda:{0}'.format(local_rank))
-        rccl = {'backend': dist.get_backend(), 'rccl_ranks': dist.get_world_size(),
-                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()), 'rehearsal_on_one_gpu': rehearsal}
-
-    cfg = dict(synth.CONFIGS[args.config])
+    rank, world, local_rank, comm, dist = ctx['rank'], ctx['world'], ctx['local_rank'], ctx['comm'], ctx['dist']
+    cfg = dict(synth.CONFIGS[config])
     p = cfg['p']
-    rate = 500 if args.config == 'c4' else 1
+    rate = 500 if config == 'c4' else 1
     n_genes = args.genes if args.genes > 0 else cfg['n_genes']
-    # every rank gets the same total gene length (the generator's lengths are a cheap pure function of the gene id)
-    all_len = [synth.gene_length(cfg['seed'], g, cfg['l_min'], cfg['l_max']) for g in range(n_genes)] if world > 1 else None
-    parts = partition_by_length(all_len, world) if world > 1 else [list(range(n_genes))]
+    # every rank gets the same predicted cost (the generator's lengths are a cheap pure function of the gene id)
+    if world > 1:
+        all_len = [synth.gene_length(cfg['seed'], g, cfg['l_min'], cfg['l_max']) for g in range(n_genes)]
+        parts = partition_by_cost(all_len, world, p=p, downsample_rate=rate)
+    else:
+        parts = [list(range(n_genes))]
     my_genes = parts[rank] if rank < len(parts) else []
     t_gen = time.time()
     packed, lengths, reads, _ = synth.synth_packed(cfg['seed'], my_genes, p, cfg['l_min'], cfg['l_max'],
@@ -254,35 +418,41 @@ def main():
     t_up = time.time()
     eng.load_packed(packed, lengths, p, reads, global_ids=np.asarray(my_genes, dtype=np.int64), n_total=n_genes)
     t_up = time.time() - t_up
-    del packed
+    keep_packed = rank == 0 and world == 1 and config == 'c2'              # the float64 dict of end_to_end / the tie count are made from it
+    if not keep_packed:
+        packed = None
 
     def sync():
         torch.cuda.synchronize()
         comm.Barrier()
         torch.cuda.synchronize()
 
-    init_ms = []
+    init_ms, fetch_s = [], []
 
     def step():
         eng.initialize()
-        init_ms.append(eng.dev.last_init_ms())
+        init_ms.append(eng.dev.last_init_ms() if eng.n_local > 0 else 0.0)
         for i in range(args.iters):
             eng.iterate(i, want_estimates=False)
+        tf = time.perf_counter()
+        eng.fetch_state()                                               # final rho / x_adj / x_weighted / flags: D2H inside the clock
+        fetch_s.append(time.perf_counter() - tf)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
 
-    split = eng.dev.split_length()
+    split = eng.dev.split_length() if eng.n_local > 0 else 0
     tiny = eng.dev.tiny_length() if split > 0 else 0
     wide = lengths > split if split > 0 else np.ones(len(lengths), dtype=bool)
     pair = (lengths <= tiny) & ~wide                                    # class 2: one wavefront per gene, two genes per workgroup
     kernel_ms, narrow_ms, pair_ms, all_traces, eng_span = [], [], [], [], []
-    pick = parity_sample(lengths, args.parity_genes) if (args.parity_genes > 0 and len(lengths) > 0) else None
+    pick = parity_sample(lengths, n_parity) if (n_parity > 0 and len(lengths) > 0) else None
     eng.history_rows = pick
     init_ms.clear()
+    fetch_s.clear()
     sync()
     t0 = time.time()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
         kernel_ms += [c[0] for c in eng.class_ms]
         narrow_ms += [c[1] for c in eng.class_ms]
@@ -292,118 +462,250 @@ def main():
     sync()
     dt = time.time() - t0
 
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if rehearsal else 'cuda')
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if ctx['rehearsal'] else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        counts = [None] * world
+        dist.all_gather_object(counts, (len(my_genes), int(wide.sum()), int((~wide & ~pair).sum()), int(pair.sum()), float(np.sum(lengths))))
+    else:
+        counts = [(len(my_genes), int(wide.sum()), int((~wide & ~pair).sum()), int(pair.sum()), float(np.sum(lengths)))]
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        value = n_genes * args.steps / dt
+    value = n_genes * steps / dt
+    name0 = eng.dev.class_kernel_name(0)
+    out = {
+        'metric': 'genes/sec (20k genes x 10 samples, 5 iters)' if config == 'c2'
+                  else 'genes/sec (50k genes x 50 samples, downsample-grid 500, 5 iters)',
+        'value': value, 'unit': 'genes/sec', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'config {0}: {1} synthetic genes x {2} samples, L~U[{3},{4}], {5} DegNorm iters, nmf_iter {6}{7}, '
+                               'fp32 coverage in HBM, fp64 arithmetic'
+                               .format(2 if config == 'c2' else 4, n_genes, p, cfg['l_min'], cfg['l_max'], args.iters,
+                                       args.nmf_iter, ', take-every {0}'.format(rate) if rate > 1 else ''),
+                   'genes_per_gpu': len(my_genes),
+                   'sharding': 'cost-balanced gene partition (utils.partition_by_cost), 1 all-reduce of 3p+4 f64 per outer iter',
+                   'per_rank': [{'genes': c[0], 'wide': c[1], 'narrow': c[2], 'pair': c[3], 'total_length': c[4]} for c in counts],
+                   'step': 'initial pass + {0} outer iterations + D2H of the final rho / x_adj / x_weighted / flags '
+                           '(fetch_state {1:.2f} ms per step)'.format(args.iters, 1e3 * float(np.mean(fetch_s)))},
+        'rccl_ranks': ctx['rccl_ranks'], 'rccl': ctx['rccl'],
+    }
+    if config == 'c2':
+        # Three gene classes = three kernels per outer iteration on three streams: class 0 (genes longer than the split
+        # length, 256-thread workgroups, launched first), class 1 (128-thread workgroups, two per CU) and class 2 (the
+        # shortest genes, one wavefront per gene, two genes per 128-thread workgroup).  Classes 1 and 2 are launched
+        # right behind class 0 and take over the CUs as it drains, so the one that ends last spans the whole sweep.  The
+        # roofline object describes that kernel (the longest launch) and puts ALL kernels' work over its duration.
+        cls_mask = [wide, ~wide & ~pair, pair]
+        cls_ms = [float(np.mean(kernel_ms)), float(np.mean(narrow_ms)), float(np.mean(pair_ms)) if pair_ms else 0.0]
+        dom = int(np.argmax(cls_ms))
+        others = [c for c in range(3) if c != dom and cls_mask[c].any()]
+        mask, avg_ms, name_d = cls_mask[dom], cls_ms[dom], eng.dev.class_kernel_name(dom)
+        span_ms = float(np.mean(eng_span)) if eng_span else max(cls_ms)
+
+        def work(m):
+            # fp64 vector work of the inner passes: per column and inner iteration u.a (2p), the update (5p), the Gram
+            # update (p(p+1)) and the 1/s scaling (p); wave-instructions: p(p+1)/2 + 5p FMA/max/mul + p cvt per 64 columns
+            col_iters = float(np.mean([float(tr[m, 2].astype(np.float64).sum()) * args.nmf_iter for tr in all_traces]))
+            return col_iters * (p * p + 9.0 * p), col_iters / 64.0 * (p * (p + 1) / 2.0 + 6.0 * p)
+        flop_d, instr_d = work(mask)
+        flop_a, instr_a = work(np.ones(len(lengths), dtype=bool))
+        alg_all = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in all_traces]))
+        tflops = flop_a / (avg_ms * 1e-3) / 1e12
+        simd_cycles = lambda ms: ms * 1e-3 * 2.4e9 * 256 * 4
+        issue_peak = FP64_VECTOR_PEAK_TFLOPS * 4.0 / FP64_ISSUE_CYCLES_1WAVE
+        traffic, tinfo = pmc_traffic(config, name_d, int(mask.sum())) if (world == 1 and n_genes == cfg['n_genes']) else (None, {'refused': 'not the profiled shard'})
+        traffic_o = {eng.dev.class_kernel_name(c): (pmc_traffic(config, eng.dev.class_kernel_name(c), int(cls_mask[c].sum()))[0]
+                                                    if traffic is not None else None) for c in others}
+        traffic_all = (traffic + sum(traffic_o.values())) if (traffic is not None and all(v is not None for v in traffic_o.values())) else None
+        out['roofline'] = {
+            'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tflops / FP64_VECTOR_PEAK_TFLOPS,
+            'what': 'fp64 vector work of ALL genes (every class kernel) / average launch duration of the dominant kernel: the '
+                    'class kernels are launched back to back on their own streams, the dominant one is the last to end, so its '
+                    'launch spans the whole sweep and the other kernels run INSIDE that window',
+            'kernel': name_d, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
+            'genes_in_kernel': int(mask.sum()), 'split_length': split, 'pair_length': tiny,
+            'concurrent_kernels': [{'kernel': eng.dev.class_kernel_name(c), 'genes': int(cls_mask[c].sum()),
+                                    'avg_launch_ms': cls_ms[c]} for c in others],
+            'sweep_span_ms': span_ms,
+            'dominant_kernel_own_work': {'fp64_tflops': flop_d / (avg_ms * 1e-3) / 1e12,
+                                         'frac': flop_d / (avg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                         'note': 'only the dominant kernel\'s genes over its launch duration (it has the chip to itself '
+                                                 'for only part of that time)'},
+            'issue_ceiling': {'peak': issue_peak, 'frac': tflops / issue_peak,
+                              'what': 'one wave per SIMD issues the column\'s instruction mix at {0} cycles per instruction, not 4 '
+                                      '(tools/ubench/clock_issue.hip, in-kernel clock 2.37-2.39 GHz; profiles/round2/ubench_clock_issue.txt)'
+                                      .format(FP64_ISSUE_CYCLES_1WAVE)},
+            'valu_issue_slots': {'wave_instructions': instr_a, 'slots_frac': instr_a * 4.0 / simd_cycles(avg_ms),
+                                 'what': 'fp64 wave-instructions of the passes x 4 cycles / (sweep time x 2.4 GHz x 1024 SIMDs)'},
+            'flop_per_column_iteration': p * p + 9.0 * p,
+            'traffic': traffic_all, 'traffic_info': tinfo,
+            'traffic_per_kernel': dict({name_d: traffic}, **traffic_o),
+            'traffic_rate_gbps': (traffic_all / (avg_ms * 1e-3) / 1e9) if traffic_all else None,
+            'traffic_frac_of_hbm_peak': (traffic_all / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_all else None,
+            'hbm_algorithmic': {'bytes_per_sweep': alg_all, 'rate_gbps': alg_all / (avg_ms * 1e-3) / 1e9, 'hbm_peak_gbps': HBM_PEAK_GBPS,
+                                'ratio_to_hbm_peak': alg_all / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                'what': 'SURVEY 8(d) algorithmic bytes (fp32 x and lambda re-streamed every inner iteration) / sweep time; '
+                                        'NOT a roofline fraction: the kernels keep x + lambda on chip (registers + LDS), so these bytes are '
+                                        'mostly never moved'},
+            'note': 'rank-0 shard; HIP events on the library streams around each launch'}
+    else:
+        # config 4: after the row-maxima shortcut an outer iteration reads only the sampled columns; the kernel that
+        # streams HBM is the initial ratio-SVD pass over the whole transcripts (nmf.py:109-121, :522-525); the kernel that
+        # takes most of the time is the iteration kernel, a chain of tiny dependent eigen-solves per gene
+        init_avg = float(np.mean(init_ms))
         avg_ms = float(np.mean(kernel_ms))
-        name0 = eng.dev.class_kernel_name(0)
-        out = {
-            'metric': 'genes/sec (20k genes x 10 samples, 5 iters)' if args.config == 'c2'
-                      else 'genes/sec (50k genes x 50 samples, downsample-grid 500, 5 iters)',
-            'value': value, 'unit': 'genes/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'config {0}: {1} synthetic genes x {2} samples, L~U[{3},{4}], {5} DegNorm iters, nmf_iter {6}{7}, '
-                                   'fp32 coverage in HBM, fp64 arithmetic'
-                                   .format(2 if args.config == 'c2' else 4, n_genes, p, cfg['l_min'], cfg['l_max'], args.iters,
-                                           args.nmf_iter, ', take-every {0}'.format(rate) if rate > 1 else ''),
-                       'genes_per_gpu': len(my_genes),
-                       'sharding': 'length-balanced gene partition, 1 all-reduce of 3p+3 f64 per outer iter'},
-            'rccl': rccl,
-        }
-        if args.config == 'c2':
-            # Three gene classes = three kernels per outer iteration on three streams: class 0 (genes longer than the split
-            # length, 256-thread workgroups, launched first), class 1 (128-thread workgroups, two per CU) and class 2 (the
-            # shortest genes, one wavefront per gene, two genes per 128-thread workgroup).  Classes 1 and 2 are launched
-            # right behind class 0 and take over the CUs as it drains, so the one that ends last spans the whole sweep.  The
-            # roofline object describes that kernel (the longest launch) and puts ALL kernels' work over its duration.
-            cls_mask = [wide, ~wide & ~pair, pair]
-            cls_ms = [float(np.mean(kernel_ms)), float(np.mean(narrow_ms)), float(np.mean(pair_ms)) if pair_ms else 0.0]
-            dom = int(np.argmax(cls_ms))
-            others = [c for c in range(3) if c != dom and cls_mask[c].any()]
-            mask, avg_ms, name_d = cls_mask[dom], cls_ms[dom], eng.dev.class_kernel_name(dom)
-            span_ms = float(np.mean(eng_span)) if eng_span else max(cls_ms)
+        alg_init = 8.0 * p * float(lengths.sum())                           # init pass 8 p L_g per gene
+        sampled = float(np.mean([tr[:, 0].astype(np.float64).sum() for tr in all_traces]))
+        calls = float(np.mean([tr[:, 1].astype(np.float64).sum() for tr in all_traces]))
+        solves = calls * (args.nmf_iter + 1)                                # nmf.py:90-101: T + 1 rank-one approximations per nmf() call
+        steps_pw = float(np.mean([tr[:, 7].astype(np.float64).sum() for tr in all_traces]))
+        out['roofline'] = {
+            'bound': 'hbm', 'achieved': alg_init / (init_avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': alg_init / (init_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'traffic': None,
+            'kernel': eng.dev.init_kernel_name(), 'avg_launch_ms': init_avg, 'launches_timed': len(init_ms),
+            'algorithmic_bytes_per_launch': alg_init,
+            'share_of_step': {'initial_pass_ms': init_avg, 'iteration_kernel_ms': avg_ms * args.iters, 'step_ms': dt / steps * 1e3},
+            'iteration_kernel': iteration_kernel_bound(eng, name0, avg_ms, len(kernel_ms), sampled, calls, solves, steps_pw, lengths, p, rate),
+            'shortcut': 'max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): per-iteration full-length scans removed; without it SURVEY 8(d) '
+                        'counts 8 p L_g per gene and outer iteration = {0:.3e} B per launch'.format(alg_init),
+            'note': 'rank-0 shard; HIP events on the library stream'}
+    out['setup'] = {'synth_s': t_gen, 'upload_s': t_up}
+    out['parity'] = parity_check(eng, pick, cfg, p, my_genes, lengths, split, args.nmf_iter, rate) if pick is not None else None
+    final_scale = np.copy(eng.scale_factors)
+    try:
+        eng.dev.close()                                                 # free the shard before the follow-up runs open their own handles
+    except Exception:
+        pass
+    if world == 1 and n_cpu > 0:
+        out['cpu_baseline'], ref, covs, rd = cpu_baseline(cfg, config, p, args.nmf_iter, args.iters, rate, n_cpu, n_single)
+        if out['parity'] is not None:
+            out['parity']['chain'] = chain_parity(ref, covs, rd, args.nmf_iter, args.iters, rate, local_rank)
+        del ref, covs, rd
+    else:
+        out['cpu_baseline'] = None
+    if keep_packed and out['parity'] is not None and n_genes == cfg['n_genes']:
+        out['parity']['tie_sensitive'] = tie_sensitive_genes(packed, lengths, p, final_scale)
+    if keep_packed and want_e2e:
+        out['end_to_end'] = end_to_end(packed, lengths, p, reads, args.iters, args.nmf_iter, rate, local_rank)
+    return out
 
-            def work(m):
-                # fp64 vector work of the inner passes: per column and inner iteration u.a (2p), the update (5p), the Gram
-                # update (p(p+1)) and the 1/s scaling (p); wave-instructions: p(p+1)/2 + 5p FMA/max/mul + p cvt per 64 columns
-                col_iters = float(np.mean([float(tr[m, 2].astype(np.float64).sum()) * args.nmf_iter for tr in all_traces]))
-                return col_iters * (p * p + 9.0 * p), col_iters / 64.0 * (p * (p + 1) / 2.0 + 6.0 * p)
-            flop_d, instr_d = work(mask)
-            flop_a, instr_a = work(np.ones(len(lengths), dtype=bool))
-            alg_d = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter, mask) for tr in all_traces]))
-            alg_all = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in all_traces]))
-            tflops = flop_a / (avg_ms * 1e-3) / 1e12
-            simd_cycles = lambda ms: ms * 1e-3 * 2.4e9 * 256 * 4
-            issue_peak = FP64_VECTOR_PEAK_TFLOPS * 4.0 / FP64_ISSUE_CYCLES_1WAVE
-            traffic, tinfo = pmc_traffic(args.config, name_d, int(mask.sum())) if (world == 1 and n_genes == cfg['n_genes']) else (None, {'refused': 'not the profiled shard'})
-            traffic_o = {eng.dev.class_kernel_name(c): (pmc_traffic(args.config, eng.dev.class_kernel_name(c), int(cls_mask[c].sum()))[0]
-                                                        if traffic is not None else None) for c in others}
-            traffic_pair = (traffic + sum(traffic_o.values())) if (traffic is not None and all(v is not None for v in traffic_o.values())) else None
-            out['roofline'] = {
-                'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': tflops / FP64_VECTOR_PEAK_TFLOPS,
-                'what': 'fp64 vector work of ALL genes (every class kernel) / average launch duration of the dominant kernel: the '
-                        'class kernels are launched back to back on their own streams, the dominant one is the last to end, so its '
-                        'launch spans the whole sweep and the other kernels run INSIDE that window',
-                'kernel': name_d, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
-                'genes_in_kernel': int(mask.sum()), 'split_length': split, 'pair_length': tiny,
-                'concurrent_kernels': [{'kernel': eng.dev.class_kernel_name(c), 'genes': int(cls_mask[c].sum()),
-                                        'avg_launch_ms': cls_ms[c]} for c in others],
-                'sweep_span_ms': span_ms,
-                'dominant_kernel_own_work': {'fp64_tflops': flop_d / (avg_ms * 1e-3) / 1e12,
-                                             'frac': flop_d / (avg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                                             'note': 'only the dominant kernel\'s genes over its launch duration (it has the chip to itself '
-                                                     'for only part of that time)'},
-                'issue_ceiling': {'peak': issue_peak, 'frac': tflops / issue_peak,
-                                  'what': 'one wave per SIMD issues the column\'s instruction mix at {0} cycles per instruction, not 4 '
-                                          '(tools/ubench/clock_issue.hip, in-kernel clock 2.37-2.39 GHz; profiles/{1}/ubench_clock_issue.txt)'
-                                          .format(FP64_ISSUE_CYCLES_1WAVE, ROUND)},
-                'valu_issue_slots': {'wave_instructions': instr_a, 'slots_frac': instr_a * 4.0 / simd_cycles(avg_ms),
-                                     'what': 'fp64 wave-instructions of the passes x 4 cycles / (sweep time x 2.4 GHz x 1024 SIMDs)'},
-                'flop_per_column_iteration': p * p + 9.0 * p,
-                'traffic': traffic_pair, 'traffic_info': tinfo,
-                'traffic_per_kernel': dict({name_d: traffic}, **traffic_o),
-                'traffic_rate_gbps': (traffic_pair / (avg_ms * 1e-3) / 1e9) if traffic_pair else None,
-                'traffic_frac_of_hbm_peak': (traffic_pair / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_pair else None,
-                'hbm_algorithmic': {'bytes_per_sweep': alg_all, 'rate_gbps': alg_all / (avg_ms * 1e-3) / 1e9, 'hbm_peak_gbps': HBM_PEAK_GBPS,
-                                    'ratio_to_hbm_peak': alg_all / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                    'what': 'SURVEY 8(d) algorithmic bytes (fp32 x and lambda re-streamed every inner iteration) / sweep time; '
-                                            'NOT a roofline fraction: the kernels keep x + lambda on chip (registers + LDS), so these bytes are '
-                                            'mostly never moved'},
-                'note': 'rank-0 shard; HIP events on the library streams around each launch'}
+
+def iteration_kernel_bound(eng, name, avg_ms, launches, sampled, calls, solves, steps_pw, lengths, p, rate):
+    """
+    Config 4's dominant kernel (gen_rows::k_baseline_gen): per nmf() call T + 1 dependent eigen-solves of an n x n matrix
+    (n <= 10), each a chain of MFMA squarings / reductions with nothing else of the gene to overlap -- a latency chain per
+    wave.  Bound: solves per launch x warm latency of one inner iteration of a single wave / waves the chip keeps in flight.
+    """
+    d = {'kernel': name, 'avg_launch_ms': avg_ms, 'launches_timed': launches, 'active_columns_per_launch': sampled,
+         'nmf_calls_per_launch': calls, 'eigen_solves_per_launch': solves, 'power_steps_per_launch': steps_pw,
+         'bytes_needed_per_launch': 4.0 * p * float(np.ceil(lengths / float(rate)).sum()),
+         'note': 'row maxima once per upload + only the sampled columns are read (SURVEY 8(d) shortcut, declared): bound by the '
+                 'latency of ~100 tiny dependent eigen-solves per nmf() call, not by HBM'}
+    path = os.path.join(ROOT, 'profiles', ROUND, 'rows_inner_iteration_cycles.json')
+    try:
+        with open(path) as f:
+            u = json.load(f)
+        cyc = float(u['cycles_per_inner_iteration_one_wave'])
+        waves = float(u['waves_in_flight'])
+        bound_ms = solves * cyc / 2.4e9 / waves * 1e3
+        d['latency_bound'] = {'bound': 'dependent-chain latency', 'cycles_per_inner_iteration_one_wave': cyc, 'waves_in_flight': waves,
+                              'bound_ms': bound_ms, 'frac': bound_ms / avg_ms, 'source': os.path.relpath(path, ROOT)}
+    except (OSError, ValueError, KeyError):
+        d['latency_bound'] = None
+    return d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_rank(args):
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from degnorm_amd.nmf_mpi import TorchComm, LocalComm
+
+    rehearsal = args.backend == 'gloo'
+    if rehearsal:
+        local_rank = 0                                                  # all ranks share the one GPU
+    torch.cuda.set_device(local_rank)
+    under_launcher = 'TORCHELASTIC_RUN_ID' in os.environ or 'WORLD_SIZE' in os.environ
+    comm, rccl, rccl_ranks, pg = LocalComm(), None, None, None
+    if under_launcher:
+        if rehearsal:
+            dist.init_process_group('gloo')
+            comm = TorchComm(device='cpu')
         else:
-            # config 4: after the row-maxima shortcut an outer iteration reads only the sampled columns; the kernel that
-            # streams HBM is the initial ratio-SVD pass over the whole transcripts (nmf.py:109-121, :522-525)
-            init_avg = float(np.mean(init_ms))
-            alg_init = 8.0 * p * float(lengths.sum())                           # init pass 8 p L_g per gene
-            sampled = float(np.mean([tr[:, 0].astype(np.float64).sum() for tr in all_traces]))
-            out['roofline'] = {
-                'bound': 'hbm', 'achieved': alg_init / (init_avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                'frac': alg_init / (init_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'traffic': None,
-                'kernel': eng.dev.init_kernel_name(), 'avg_launch_ms': init_avg, 'launches_timed': len(init_ms),
-                'algorithmic_bytes_per_launch': alg_init,
-                'iteration_kernel': {'kernel': name0, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
-                                     'active_columns_per_launch': sampled,
-                                     'bytes_needed_per_launch': 4.0 * p * float(np.ceil(lengths / float(rate)).sum()),
-                                     'note': 'row maxima once per upload + only the sampled columns are read (SURVEY 8(d) shortcut, declared): '
-                                             'this kernel is bound by the latency of ~100 tiny dependent eigen-solves per nmf() call, not by HBM'},
-                'shortcut': 'max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): per-iteration full-length scans removed; without it SURVEY 8(d) '
-                            'counts 8 p L_g per gene and outer iteration = {0:.3e} B per launch'.format(alg_init),
-                'note': 'rank-0 shard; HIP events on the library stream'}
-        out['setup'] = {'synth_s': t_gen, 'upload_s': t_up}
-        out['parity'] = parity_check(eng, pick, cfg, p, my_genes, lengths, split, args, rate) if pick is not None else None
-        n_cpu = args.cpu_sample if args.cpu_sample >= 0 else (768 if args.config == 'c2' else 2048)
-        out['cpu_baseline'] = cpu_baseline(cfg, args.config, p, args.nmf_iter, args.iters, rate, n_cpu) if (world == 1 and n_cpu > 0) else None
-        print(json.dumps(out))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            comm = TorchComm(device='cuda:{0}'.format(local_rank))
+        pg = dist
+    elif not args.no_rccl:
+        # plain `python bench.py` at N = 1: the per-sample all-reduce still goes through RCCL (a one-rank process group), so the
+        # N = 1 line pays what every rank of an N > 1 run pays
+        try:
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:{0}'.format(_free_port()), world_size=1, rank=0,
+                                    device_id=torch.device('cuda', local_rank))
+            comm = TorchComm(device='cuda:{0}'.format(local_rank))
+            pg = dist
+        except Exception as e:                                          # no RCCL on this box: the all-reduce of one rank is the identity
+            rccl = {'backend': None, 'error': repr(e)[:200]}
+    if pg is not None:
+        rccl = {'backend': dist.get_backend(), 'rccl_ranks': dist.get_world_size(),
+                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()), 'rehearsal_on_one_gpu': rehearsal,
+                'self_launched': bool(os.environ.get('DN_BENCH_PARENT'))}
+        rccl_ranks = dist.get_world_size() if dist.get_backend() == 'nccl' else None
+    ctx = {'rank': rank, 'world': world, 'local_rank': local_rank, 'comm': comm, 'dist': pg, 'rehearsal': rehearsal,
+           'rccl': rccl, 'rccl_ranks': rccl_ranks}
 
-    if distributed:
+    n_cpu = args.cpu_sample if args.cpu_sample >= 0 else (768 if args.config == 'c2' else 2048)
+    n_single = args.cpu_single if args.cpu_single >= 0 else (64 if args.config == 'c2' else 512)
+    out = measure(args.config, args, ctx, args.steps, args.warmup, args.parity_genes, n_cpu, n_single, not args.no_end_to_end)
+    if rank == 0 and world == 1 and args.config == 'c2' and not args.no_also and args.genes <= 0:
+        # BASELINE configs[3] in the same process, after the config-2 clock has stopped (its own generation, upload, warm-up, clock)
+        sub = measure('c4', args, ctx, 3, 2, args.parity_genes, 2048 if n_cpu > 0 else 0, 512 if n_single > 0 else 0, False)
+        out['also'] = {'config 4': {k: sub[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline',
+                                                        'parity', 'cpu_baseline', 'setup')}}
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if pg is not None:
         dist.destroy_process_group()
 
 
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4'])
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=2)    # the first step after the first-ever one still carries ~18 ms of one-time host cost
+    ap.add_argument('--genes', type=int, default=0, help='total genes (default: the configuration\'s: 20000 / 50000)')
+    ap.add_argument('--iters', type=int, default=5, help='outer DegNorm iterations per step')
+    ap.add_argument('--nmf-iter', type=int, default=100)
+    ap.add_argument('--cpu-sample', type=int, default=-1, help='genes in the CPU-baseline sample (0 = skip; default 768 / 2048)')
+    ap.add_argument('--cpu-single', type=int, default=-1, help='genes of that sample also run on ONE thread (0 = skip; default 64 / 512)')
+    ap.add_argument('--parity-genes', type=int, default=160, help='genes in the post-clock parity sample (0 = skip)')
+    ap.add_argument('--no-end-to-end', action='store_true', help='skip the GeneNMFOA.fit() end-to-end timing (config 2, N = 1)')
+    ap.add_argument('--no-also', action='store_true', help='skip the config-4 measurement appended to the default config-2 line')
+    ap.add_argument('--no-rccl', action='store_true', help='N = 1 without torchrun: do not open a one-rank RCCL process group')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='collective backend of the ranks: nccl = RCCL (the measured path); gloo only to rehearse N > 1 on ONE GPU '
+                         '(every rank on device 0; the line is then marked "rehearsal")')
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, argv)                            # parent: nothing below this line touches torch or the GPU
+    run_rank(args)
+    return 0
+
+
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

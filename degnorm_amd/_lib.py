@@ -195,6 +195,12 @@ class Device:
                                           _p(status, ctypes.c_int32)))
         return est, cov, status
 
+    def init_status(self):
+        """Per-gene status of the initial pass alone (re-runs it; the error path of a device-side initialisation)."""
+        status = np.zeros(self.n, dtype=np.int32)
+        _check(self.lib.dn_ratio_svd_sums(self.h, None, None, _p(status, ctypes.c_int32)))
+        return status
+
     def init_begin(self, reads):
         x = np.ascontiguousarray(reads, dtype=np.float64)
         if x.shape != (self.n, self.p):
@@ -202,7 +208,7 @@ class Device:
         _check(self.lib.dn_init_begin(self.h, _p(x, ctypes.c_double)))
 
     def init_partials(self):
-        out = np.zeros(3 * self.p + 3)
+        out = np.zeros(3 * self.p + 4)
         _check(self.lib.dn_init_partials(self.h, _p(out, ctypes.c_double)))
         return out
 
@@ -247,7 +253,7 @@ class Device:
         _check(self.lib.dn_outer_begin(self.h, _p(xw, ctypes.c_double), int(degnorm_iter)))
 
     def outer_partials(self):
-        out = np.zeros(3 * self.p + 3)
+        out = np.zeros(3 * self.p + 4)
         _check(self.lib.dn_outer_partials(self.h, _p(out, ctypes.c_double)))
         return out
 

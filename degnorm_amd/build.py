@@ -22,7 +22,14 @@ P_LIST = list(range(2, int(os.environ.get('DN_P_MAX_TEMPLATED', 64)) + 1))   # k
 ARCH = 'gfx950'
 WIDE_NT = int(os.environ.get('DN_WIDE_NT', 256))     # wide-class workgroup size (csrc/dn_api.hip DN_WIDE_NT)
 NT_LIST = (WIDE_NT, 128)
+# pair build (one wavefront per gene, two genes per 128-thread workgroup): where the register tier exists (dn_kernels.hpp
+# DN_RT_MIN_P .. DN_RT_MAX_P; dn_inst.hip refuses to compile a pair unit without it).  The list is handed to dn_api.hip as the
+# DN_P_PAIR X-macro, so the dispatcher there cannot drift from what is compiled here.
+PAIR_P_LIST = [q for q in P_LIST if int(os.environ.get('DN_RT_MIN_P', 8)) <= q <= int(os.environ.get('DN_RT_MAX_P', 12))]
 EXTRA = ['-D' + d for d in os.environ.get('DN_DEFINES', '').split() if d]   # e.g. DN_DEFINES='DN_STAMP=1'
+for _k in ('DN_RT_MIN_P', 'DN_RT_MAX_P'):             # the same bounds reach the kernels that PAIR_P_LIST was derived from
+    if _k in os.environ:
+        EXTRA.append('-D{0}={1}'.format(_k, int(os.environ[_k])))
 # kernel translation units: the max-ILP machine scheduler places the independent fp64 operations of the inner pass
 # better than the default (occupancy-driven) one for this one-wave-per-SIMD kernel: +0.7 % on config 2
 SCHED = os.environ.get('DN_HIPCC_FLAGS', '-mllvm -amdgpu-sched-strategy=max-ilp').split()
@@ -67,8 +74,8 @@ def build_library(force=False, verbose=False):
             objs.append(o)
             if force or _newer(o, [inst] + hdr):
                 jobs.append([hipcc] + FLAGS + SCHED + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt), '-c', inst, '-o', o])
-    for p in [q for q in P_LIST if 8 <= q <= 12]:      # pair build (one wavefront per gene, two genes per 128-thread workgroup) where
-        o = os.path.join(OBJ, 'dn_inst_p{0}_pair.o'.format(p))      # the register tier exists (csrc/dn_api.hip DN_P_PAIR)
+    for p in PAIR_P_LIST:
+        o = os.path.join(OBJ, 'dn_inst_p{0}_pair.o'.format(p))
         objs.append(o)
         if force or _newer(o, [inst] + hdr):
             jobs.append([hipcc] + FLAGS + SCHED + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT=64', '-DDN_PAIR=1', '-c', inst, '-o', o])
@@ -87,7 +94,8 @@ def build_library(force=False, verbose=False):
     o_api = os.path.join(OBJ, 'dn_api.o')
     objs.append(o_api)
     if force or _newer(o_api, [api] + hdr):
-        jobs.append([hipcc] + FLAGS + ['-DDN_WIDE_NT={0}'.format(WIDE_NT), '-DDN_P_MAX_TEMPLATED={0}'.format(P_LIST[-1]), '-c', api, '-o', o_api])
+        jobs.append([hipcc] + FLAGS + ['-DDN_WIDE_NT={0}'.format(WIDE_NT), '-DDN_P_MAX_TEMPLATED={0}'.format(P_LIST[-1]),
+                                       '-DDN_P_PAIR(X)=' + ' '.join('X({0})'.format(q) for q in PAIR_P_LIST), '-c', api, '-o', o_api])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for out in ex.map(_run, jobs):

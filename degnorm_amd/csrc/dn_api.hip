@@ -50,7 +50,9 @@ DN_FOR_EACH_P(DN_DECL)
 
 // Pair build (dn_inst.hip -DDN_PAIR): 128-thread workgroups carrying two genes, one per wavefront, for the shortest genes;
 // compiled where the register tier exists
+#ifndef DN_P_PAIR                 // build.py passes the list it compiles (-D'DN_P_PAIR(X)=X(8) ...'): ONE source of truth
 #define DN_P_PAIR(X) X(8) X(9) X(10) X(11) X(12)
+#endif
 #define DN_DECL(P) const KernelSet *kernel_set_p##P##_pair();
 DN_P_PAIR(DN_DECL)
 #undef DN_DECL
@@ -126,14 +128,14 @@ __global__ __launch_bounds__(256) void k_row_max(const float *__restrict__ cov, 
 
 // ---------------------------------------------------------------------------------------------------
 // The outer DegNorm update on the device (nmf.py:398-399, :148-158, :575-590; nmf_mpi.py:821-838).  Per outer iteration
-// the host needs 3p + 3 numbers, not the n x p DI matrix: one wave per gene, lane i = sample i.
+// the host needs 3p + 4 numbers, not the n x p DI matrix: one wave per gene, lane i = sample i.
 //   k_outer_partials  clip rho to [0, 0.9]; untouched = (max_i rho == 0); per-sample partial sums
 //                     A = sum_touched x_w / (1 - rho), B = sum_untouched x_w, W = sum x_w; counts of untouched / failed /
 //                     unconverged genes.  Block partials, then k_outer_reduce adds them in block order (deterministic).
 //   k_outer_apply     rho[untouched] = avg_di; x_adj = x_w / (1 - rho); x_w /= norm; ran_baseline_selection[:, iter].
 // ---------------------------------------------------------------------------------------------------
 constexpr int OUT_BLOCKS = 512;
-constexpr int OUT_STRIDE = 3 * 64 + 4;          // per block: A[64] B[64] W[64] n_untouched n_failed n_noconv (pad)
+constexpr int OUT_STRIDE = 3 * 64 + 4;          // per block: A[64] B[64] W[64] n_untouched n_failed n_noconv n_flagged
 
 __device__ __forceinline__ double wave_max_d(double v)
 {
@@ -144,13 +146,13 @@ __device__ __forceinline__ double wave_max_d(double v)
 
 __global__ __launch_bounds__(256) void k_outer_partials(const double *__restrict__ rho_raw, double *__restrict__ rho_c,
                                                         const double *__restrict__ xw, const int32_t *__restrict__ trace,
-                                                        double *__restrict__ part, int n, int p)
+                                                        const int32_t *__restrict__ flags, double *__restrict__ part, int n, int p)
 {
     __shared__ double sm[4][3][64];
-    __shared__ double cnt[4][3];
+    __shared__ double cnt[4][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
-    double a = 0.0, b = 0.0, ws = 0.0, nu = 0.0, nf = 0.0, nc = 0.0;
+    double a = 0.0, b = 0.0, ws = 0.0, nu = 0.0, nf = 0.0, nc = 0.0, nr = 0.0;
     for (int g = blockIdx.x * 4 + w; g < n; g += nw) {
         double r = 0.0, x = 0.0;
         if (lane < p) {
@@ -167,15 +169,16 @@ __global__ __launch_bounds__(256) void k_outer_partials(const double *__restrict
         if (lane == 0) {
             const int st = trace[(size_t) g * dn::TRACE_LEN + 6];
             nu += untouched ? 1.0 : 0.0; nf += st != 0 ? 1.0 : 0.0; nc += st == dn::ST_NO_CONVERGENCE ? 1.0 : 0.0;
+            nr += flags[g] != 0 ? 1.0 : 0.0;                              // ran_baseline_selection[:, i].sum() (nmf.py:571)
         }
     }
     sm[w][0][lane] = a; sm[w][1][lane] = b; sm[w][2][lane] = ws;
-    if (lane == 0) { cnt[w][0] = nu; cnt[w][1] = nf; cnt[w][2] = nc; }
+    if (lane == 0) { cnt[w][0] = nu; cnt[w][1] = nf; cnt[w][2] = nc; cnt[w][3] = nr; }
     __syncthreads();
     if (threadIdx.x < 192) {
         const int k = threadIdx.x >> 6, i = threadIdx.x & 63;
         part[(size_t) blockIdx.x * OUT_STRIDE + 64 * k + i] = ((sm[0][k][i] + sm[1][k][i]) + sm[2][k][i]) + sm[3][k][i];
-    } else if (threadIdx.x < 195) {
+    } else if (threadIdx.x < 196) {
         const int k = threadIdx.x - 192;
         part[(size_t) blockIdx.x * OUT_STRIDE + 192 + k] = ((cnt[0][k] + cnt[1][k]) + cnt[2][k]) + cnt[3][k];
     }
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void k_init_partials(const double *__restrict_
                                                        double *__restrict__ part, int n, int p)
 {
     __shared__ double sm[4][3][64];
-    __shared__ double cnt[4][3];
+    __shared__ double cnt[4][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
     double a = 0.0, b = 0.0, nl = 0.0, nb = 0.0;
@@ -205,12 +208,12 @@ __global__ __launch_bounds__(256) void k_init_partials(const double *__restrict_
         if (lane == 0) { nl += low ? 1.0 : 0.0; nb += status[g] != 0 ? 1.0 : 0.0; }
     }
     sm[w][0][lane] = a; sm[w][1][lane] = b; sm[w][2][lane] = 0.0;
-    if (lane == 0) { cnt[w][0] = nl; cnt[w][1] = nb; cnt[w][2] = 0.0; }
+    if (lane == 0) { cnt[w][0] = nl; cnt[w][1] = nb; cnt[w][2] = 0.0; cnt[w][3] = 0.0; }
     __syncthreads();
     if (threadIdx.x < 192) {
         const int k = threadIdx.x >> 6, i = threadIdx.x & 63;
         part[(size_t) blockIdx.x * OUT_STRIDE + 64 * k + i] = ((sm[0][k][i] + sm[1][k][i]) + sm[2][k][i]) + sm[3][k][i];
-    } else if (threadIdx.x < 195) {
+    } else if (threadIdx.x < 196) {
         const int k = threadIdx.x - 192;
         part[(size_t) blockIdx.x * OUT_STRIDE + 192 + k] = ((cnt[0][k] + cnt[1][k]) + cnt[2][k]) + cnt[3][k];
     }
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void k_scale_reads(const double *__restrict__ 
 __global__ __launch_bounds__(256) void k_outer_reduce(const double *__restrict__ part, double *__restrict__ out, int nblocks, int p)
 {
     const int t = threadIdx.x;
-    if (t >= 195) return;
+    if (t >= 196) return;
     double s = 0.0;
     for (int b = 0; b < nblocks; b++) s += part[(size_t) b * OUT_STRIDE + t];
     const int k = t >> 6, i = t & 63;
@@ -475,28 +478,34 @@ int dn_destroy(dn_handle h)
     return DN_OK;
 }
 
-// Scratch slots and LDS tier of one gene class for genes of up to `cols` active columns.
+// Scratch slots and LDS tier of one gene class for genes of up to `cols` active columns.  The new scratch is allocated
+// FIRST and swapped in only on success: a failed (re)size leaves the class -- and the handle's alias of class 0's slots --
+// exactly as it was, still valid.
 static int size_class(dn_handle h, dn_handle_s::GeneClass &C, int32_t cols)
 {
     const int32_t p = h->p;
-    if (C.d_ws) { (void) hipFree(C.d_ws); C.d_ws = nullptr; }
     int per_cu = C.ks->blocks_per_cu(0);
     if (per_cu < 1) per_cu = 1;
     const int units = std::max(1, C.ks->units);          // genes a workgroup carries at once: a slot and an LDS tile per unit
-    C.slots = (int) std::min<int64_t>(((int64_t) C.n + units - 1) / units * units, (int64_t) per_cu * h->n_cus * units);
-    C.S = (cols + 63) & ~63;
+    int slots = (int) std::min<int64_t>(((int64_t) C.n + units - 1) / units * units, (int64_t) per_cu * h->n_cus * units);
+    const int32_t S = (cols + 63) & ~63;
     // slot: Fs, Fb (fp32, p x S) + x + lambda spill (fp64 [p][S]) + s_start, residual profile, A^T u (fp64 [S])
-    C.slot_bytes = (int64_t) C.S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double)) + (int64_t) C.ks->slot_extra_bytes;
+    const int64_t slot_bytes = (int64_t) S * ((int64_t) p * (2 * sizeof(float) + sizeof(double)) + 3 * sizeof(double)) + (int64_t) C.ks->slot_extra_bytes;
     {
         // one very long gene sizes every slot of its class: keep the scratch within a share of free HBM by
-        // running fewer persistent workgroups rather than failing
+        // running fewer persistent workgroups rather than failing (the old scratch, still allocated, counts as free)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const int64_t budget = (int64_t) (free_b / 3);
-        if (C.slot_bytes > budget) return fail(DN_E_INVALID, "a gene is too long for the device scratch (" + std::to_string(C.S) + " columns)");
-        C.slots = (int) std::max<int64_t>(units, std::min<int64_t>(C.slots, budget / C.slot_bytes / units * units));
+        const int64_t budget = (int64_t) ((free_b + (C.d_ws ? (size_t) C.slot_bytes * (size_t) std::max(C.slots, 1) : 0)) / 3);
+        if (slot_bytes > budget) return fail(DN_E_INVALID, "a gene is too long for the device scratch (" + std::to_string(S) + " columns)");
+        slots = (int) std::max<int64_t>(units, std::min<int64_t>(slots, budget / slot_bytes / units * units));
     }
-    HIP_TRY(hipMalloc(&C.d_ws, (size_t) C.slot_bytes * (size_t) std::max(C.slots, 1)));
+    char *ws = nullptr;
+    HIP_TRY(hipMalloc(&ws, (size_t) slot_bytes * (size_t) std::max(slots, 1)));
+    const bool aliased = (h->d_ws == C.d_ws);
+    if (C.d_ws) (void) hipFree(C.d_ws);
+    C.d_ws = ws; C.slots = slots; C.S = S; C.slot_bytes = slot_bytes;
+    if (aliased && &C == &h->cls[0]) h->d_ws = ws;
     // lambda LDS tier: whatever of the CU's 160 KiB is left per resident workgroup after the static part
     const int64_t lds_per_block = (160 * 1024) / per_cu - (int64_t) C.ks->static_lds_bytes - 256;
     const int64_t ps = p + (p & 1);                        // LDS column stride in doubles (16-B aligned)
@@ -957,7 +966,7 @@ int dn_init_partials(dn_handle h, double *partials)
                        (int) h->n, (int) h->p);
     hipLaunchKernelGGL(k_outer_reduce, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_pvec, blocks, (int) h->p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(partials, h->d_pvec, sizeof(double) * (size_t) (3 * h->p + 3), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(partials, h->d_pvec, sizeof(double) * (size_t) (3 * h->p + 4), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return DN_OK;
 }
@@ -998,11 +1007,11 @@ int dn_outer_partials(dn_handle h, double *partials)
     if (!partials) return fail(DN_E_INVALID, "dn_outer_partials: null output");
     HIP_TRY(hipSetDevice(h->device));
     const int blocks = (int) std::min<int64_t>(OUT_BLOCKS, (h->n + 3) / 4);
-    hipLaunchKernelGGL(k_outer_partials, dim3(blocks), dim3(256), 0, h->stream, h->d_rho, h->d_rhoc, h->d_xw, h->d_trace, h->d_part,
+    hipLaunchKernelGGL(k_outer_partials, dim3(blocks), dim3(256), 0, h->stream, h->d_rho, h->d_rhoc, h->d_xw, h->d_trace, h->d_flags, h->d_part,
                        (int) h->n, (int) h->p);
     hipLaunchKernelGGL(k_outer_reduce, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_pvec, blocks, (int) h->p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(partials, h->d_pvec, sizeof(double) * (size_t) (3 * h->p + 3), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(partials, h->d_pvec, sizeof(double) * (size_t) (3 * h->p + 4), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return DN_OK;
 }

@@ -11,6 +11,10 @@
 #define DN_NT 64
 #endif
 
+#if defined(DN_PAIR) && !DN_REG_TIER
+#error "the pair build exists only where the register tier does (DN_RT_MIN_P <= p <= DN_RT_MAX_P): fix PAIR_P_LIST in build.py"
+#endif
+
 #define DN_MAX_DEVICES 64
 #define DN_CAT_(a, b) a##b
 #define DN_CAT(a, b) DN_CAT_(a, b)

@@ -1,26 +1,26 @@
 """
 GeneNMFOA -- host-side mirror of the reference's NMF over-approximation driver (degnorm/nmf.py:10-711)
-whose per-gene arithmetic runs in hand-written HIP kernels on an MI355X (libdegnorm_amd.so).
+whose arithmetic runs in hand-written HIP kernels on an MI355X (libdegnorm_amd.so).
 
 Same constructor, ``run(cov_dat, reads_dat)`` (plus the ``fit`` alias BASELINE.json asks for),
 ``save_results(...)`` and post-run attributes as the reference, so ``from degnorm_amd.nmf import *`` can
 replace ``from degnorm.nmf import *`` in degnorm/__main__.py:11.
 
-What stays on the host (float64 numpy, O(n_genes x p) per outer iteration): the DI clip (nmf.py:398-399),
-correct_di_scores (nmf.py:148-158) and the read-count / scale-factor update (nmf.py:575-590).
-What runs on the device: ratio_svd (nmf.py:109-121), adjust_coverage_curves (nmf.py:142-146, folded into
-the loads) and baseline_selection with its nmf() calls (nmf.py:189-372) for every gene.
+``run()`` is a single-rank ``ShardedNMFOA`` (nmf_mpi.py of this package, ``LocalComm``): the engine bench.py measures.
+On the device: ratio_svd (nmf.py:109-121) and the initial normalisation (:524-535), adjust_coverage_curves (:142-146,
+folded into the loads), baseline_selection with its nmf() calls (:189-372) for every gene, the DI clip (:398-399),
+correct_di_scores (:148-158) and the read-count / scale-factor update (:575-590).  The host packs the coverage dict once
+(threads, float64 -> float32 staging, dn_upload_ragged), sees 3p + 4 numbers per outer iteration, and copies rho / x_adj /
+x_weighted / ran_baseline_selection back once at the end (fetch_state) plus the estimates of the last iteration.
 
 There is no CPU fallback: if the HIP library or a GPU is missing, run() raises.
 """
 import logging
 import os
-import pickle as pkl
+import time
 import warnings
 
 import numpy as np
-
-from . import _lib
 
 __all__ = ['GeneNMFOA']
 
@@ -32,8 +32,9 @@ class GeneNMFOA(object):
                  device=None):
         """
         Same parameters as the reference constructor (nmf.py:12-53).  ``n_jobs`` is accepted for
-        compatibility and only sizes the host packing threads; ``device`` (extra) picks the HIP device
-        (default: LOCAL_RANK or 0).
+        compatibility: a value > 1 is the number of host packing threads, the default 1 (the reference's
+        --proc-per-node default) lets the library use the box's cores, at most 16; ``device`` (extra) picks the
+        HIP device (default: LOCAL_RANK or 0).
         """
         self.degnorm_iter = abs(int(degnorm_iter))
         self.nmf_iter = abs(int(nmf_iter))
@@ -66,6 +67,8 @@ class GeneNMFOA(object):
         self.traces = []                   # per outer iteration: (n_genes x TRACE_LEN) int32 device traces
         self.kernel_ms = []                # per outer iteration: device time of the main kernel
         self._dev = None
+        self._engine = None                # the single-rank ShardedNMFOA behind run()
+        self.timings = None                # wall time per stage of the last run()
 
     # ------------------------------------------------------------------------------------------- #
     def check_input(self, cov_mats):
@@ -82,20 +85,6 @@ class GeneNMFOA(object):
             if not np.min(li_vec) >= self.downsample_rate:
                 raise ValueError('downsample_rate is too large; take-every size > at least one gene.')
 
-    def _offsets_for_iteration(self, i, rng):
-        """Systematic-sample start per gene (nmf.py:422).  Explicit offsets win (parity tests)."""
-        if self.downsample_rate <= 1:
-            return None
-        if self.downsample_offsets is not None:
-            return np.asarray(self.downsample_offsets[i], dtype=np.int64)
-        return rng.randint(0, self.downsample_rate, size=self.n_genes).astype(np.int64)
-
-    def correct_di_scores(self):
-        """Genes that were not run through baseline selection get the sample-average DI (nmf.py:148-158)."""
-        untouched = self.rho.max(axis=1) == 0
-        if np.sum(untouched) > 0:
-            self.rho[untouched, :] = 1 - (self.x_weighted.sum(axis=0) / self.x_adj.sum(axis=0))
-
     # ------------------------------------------------------------------------------------------- #
     def run(self, cov_dat, reads_dat):
         """
@@ -104,7 +93,12 @@ class GeneNMFOA(object):
         :param cov_dat: OrderedDict {gene: (p x L_g) coverage matrix}
         :param reads_dat: (n_genes x p) read counts
         :return: list of (p x L_g) float64 estimated coverage matrices, in gene order
+
+        ``self.timings`` (extra) holds the wall time of each stage: ``pack_upload_s`` (coverage dict -> float32 staging ->
+        HBM, read counts), ``run_s`` (initial pass + the outer iterations), ``estimates_s`` (rebuild + D2H of the last
+        iteration's estimates), ``fetch_state_s`` (D2H of rho / x_adj / x_weighted / flags).
         """
+        from .nmf_mpi import ShardedNMFOA, LocalComm
         self.n_genes = len(cov_dat)
         self.genes = list(cov_dat.keys())
         self.x = np.array(reads_dat, dtype=np.float64)
@@ -113,78 +107,51 @@ class GeneNMFOA(object):
         self.ran_baseline_selection = np.zeros(shape=[self.n_genes, self.degnorm_iter]).astype(bool)
         self.check_input(cov_mats)
 
-        dev = _lib.Device(self.device)
-        self._dev = dev
-        dev.hint_downsample(self.downsample_rate)
+        t0 = time.perf_counter()
+        eng = ShardedNMFOA(comm=LocalComm(), device=self.device, degnorm_iter=self.degnorm_iter,
+                           downsample_rate=self.downsample_rate, min_high_coverage=self.min_high_coverage,
+                           nmf_iter=self.nmf_iter, bins=self.bins, skip_baseline_selection=self.skip_baseline_selection,
+                           random_state=self.random_state)
+        eng.gene_names = self.genes                       # failures and unconverged solves are reported by name
+        eng.downsample_offsets = self.downsample_offsets  # optional explicit systematic-sample starts
+        if self.degnorm_iter == 0:
+            eng.device_outer = False                      # nothing to iterate: the initial DI scores come back as they are
+        self._engine = eng
+        self._dev = eng.dev                               # raises here when the HIP library or a GPU is missing
         if self.solver_step_cap is not None:
-            dev.set_solver_step_cap(self.solver_step_cap)
-        dev.upload(cov_mats, n_threads=max(self.n_jobs, 0))
-        if dev.inexact:
+            eng.dev.set_solver_step_cap(self.solver_step_cap)
+        eng.load(cov_mats, self.x, n_threads=self.n_jobs if self.n_jobs > 1 else 0)
+        if eng.dev.inexact:
             warnings.warn('{0} coverage values are not exactly representable in float32; '
-                          'they were rounded on upload.'.format(dev.inexact))
+                          'they were rounded on upload.'.format(eng.dev.inexact))
+        t1 = time.perf_counter()
 
-        # ---- initialisation (nmf.py:521-535) ----
-        est_sums, cov_sums, status = dev.ratio_svd_sums()
-        if np.any(status == -4):
-            raise ValueError('the rank-1 SVD did not converge within the step cap on {0} gene(s) during initialisation '
-                             '(ARPACK would raise ArpackNoConvergence): first {1}'
-                             .format(int(np.sum(status == -4)), self.genes[int(np.argmax(status == -4))]))
-        if np.any(status != 0):
-            raise ValueError('rank-1 SVD failed on {0} gene(s) during initialisation (all-zero coverage?): first {1}'
-                             .format(int(np.sum(status != 0)), self.genes[int(np.argmax(status != 0))]))
-        self.rho = 1 - (cov_sums / (est_sums + 1))
-        low_di_gene = self.rho.max(axis=1) < 0.1
-        count_sums = self.x[low_di_gene, :].sum(axis=0) if np.any(low_di_gene) else self.x.sum(axis=0)
-        self.norm_factors = count_sums / np.median(count_sums)
-        self.x_weighted = self.x / self.norm_factors
-        self.scale_factors = np.copy(self.norm_factors)
+        eng.initialize()                                  # nmf.py:521-535
         logging.info('Initial sequencing depth scale factors -- \n\t{0}'
-                     .format(', '.join([str(x) for x in self.scale_factors])))
-
-        rng = np.random.RandomState(self.random_state)
-        self.traces, self.kernel_ms = [], []
-        estimates = None
-
-        # ---- DegNorm iterations (nmf.py:558-596) ----
-        for i in range(self.degnorm_iter):
+                     .format(', '.join([str(x) for x in eng.scale_factors])))
+        estimates, t_est = None, 0.0
+        for i in range(self.degnorm_iter):                # nmf.py:558-596
             last = i == self.degnorm_iter - 1
-            rho, flags, trace = dev.baseline_iteration(
-                self.scale_factors, nmf_iter=self.nmf_iter, bins=self.bins, min_high_coverage=self.min_high_coverage,
-                downsample_rate=self.downsample_rate, skip_baseline_selection=self.skip_baseline_selection,
-                want_estimates=last, ds_start=self._offsets_for_iteration(i, rng))
-            self.traces.append(trace)
-            self.kernel_ms.append(dev.last_kernel_ms())
-            bad = trace[:, 6] != 0
-            if np.any(bad):
-                logging.warning('DegNorm iteration {0} -- {1} gene(s) hit a degenerate factorization '
-                                '(reference would raise); their DI scores were left at 0.'.format(i + 1, int(bad.sum())))
-            noconv = np.flatnonzero(trace[:, 6] == -4)
-            if noconv.size:
-                logging.warning('DegNorm iteration {0} -- the rank-1 SVD did not converge within the step cap on {1} gene(s) '
-                                '(ARPACK would raise ArpackNoConvergence); not used, DI left at 0: {2}{3}'
-                                .format(i + 1, noconv.size, ', '.join(self.genes[k] for k in noconv[:10]),
-                                        ' ...' if noconv.size > 10 else ''))
-
-            rho[rho > 0.9] = 0.9                                    # nmf.py:398
-            rho[rho < 0.] = 0.                                      # nmf.py:399
-            self.rho = rho
-            self.ran_baseline_selection[:, i] = flags               # nmf.py:403
+            eng.iterate(i, want_estimates=last)
             if not self.skip_baseline_selection:
                 logging.info('DegNorm iteration {0} -- {1} genes sent through baseline selection'
-                             .format(i + 1, np.sum(self.ran_baseline_selection[:, i])))
-
-            self.x_adj = self.x_weighted / (1 - self.rho)           # nmf.py:575
-            self.correct_di_scores()                                # nmf.py:578
-            self.x_adj = self.x_weighted / (1 - self.rho)           # nmf.py:581
-            col = self.x_adj.sum(axis=0)
-            self.norm_factors = col / np.median(col)                # nmf.py:584
-            self.x_weighted = self.x_weighted / self.norm_factors   # nmf.py:587
-            if last:
-                estimates = dev.fetch_estimates()                   # built with this iteration's scale factors
-            self.scale_factors = self.scale_factors * self.norm_factors   # nmf.py:590
+                             .format(i + 1, eng.n_flagged[-1]))
             logging.info('DegNorm iteration {0} -- sequencing depth scale factors: \n\t{1}'
-                         .format(i + 1, ', '.join([str(x) for x in self.scale_factors])))
+                         .format(i + 1, ', '.join([str(x) for x in eng.scale_factors])))
+            if last:
+                te = time.perf_counter()
+                estimates = eng.dev.fetch_estimates()     # built with this iteration's scale factors (nmf.py:601)
+                t_est = time.perf_counter() - te
+        t2 = time.perf_counter()
+        eng.fetch_state()
+        t3 = time.perf_counter()
 
+        self.rho, self.x_adj, self.x_weighted = eng.rho, eng.x_adj, eng.x_weighted
+        self.norm_factors, self.scale_factors = eng.norm_factors, eng.scale_factors
+        if self.degnorm_iter > 0:
+            self.ran_baseline_selection = np.asarray(eng.ran_baseline_selection, dtype=bool)
+        self.traces, self.kernel_ms = eng.traces, eng.kernel_ms
+        self.timings = {'pack_upload_s': t1 - t0, 'run_s': t2 - t1 - t_est, 'estimates_s': t_est, 'fetch_state_s': t3 - t2}
         self.fitted = True
         if estimates is None:                                       # degnorm_iter == 0: ratio-SVD estimates are not kept
             estimates = [np.array(c, dtype=np.float64) for c in cov_mats]

@@ -5,8 +5,8 @@ The reference partitions genes over MPI ranks (nmf_mpi.py:603-629), has rank 0 r
 coverage matrix each iteration (:745-760) and collect every estimate and DI row (:796-815): ~GBs of pickle
 through rank 0 per iteration although the only cross-gene coupling is a length-p vector.  Here each rank
 (one process per GPU) uploads its contiguous gene chunk once, keeps it resident in HBM, and per outer
-iteration contributes 3p float64 partial sums to ONE all-reduce (RCCL over xGMI when the process group
-is "nccl"; gloo on CPU for tests):
+iteration contributes 3p + 4 float64 (three per-sample partial sums and four counters) to ONE all-reduce (RCCL over
+xGMI when the process group is "nccl"; gloo on CPU for tests):
 
     A[i] = sum over genes with rho.max() > 0 of x_w[g,i] / (1 - rho[g,i])
     B[i] = sum over genes with rho.max() == 0 of x_w[g,i]            (genes correct_di_scores rewrites)
@@ -185,6 +185,8 @@ class ShardedNMFOA(object):
         self.n_total = 0
         self.global_ids = None
         self.p = 0
+        self.gene_names = None                            # optional: names of the local genes, for error / warning texts
+        self.n_flagged = []                               # per outer iteration: genes sent through baseline selection (all ranks)
 
     @property
     def dev(self):
@@ -193,12 +195,13 @@ class ShardedNMFOA(object):
         return self._dev
 
     # -- data -------------------------------------------------------------------------------------
-    def load(self, cov_mats, reads, global_ids=None, n_total=None, p=None):
+    def load(self, cov_mats, reads, global_ids=None, n_total=None, p=None, n_threads=0):
         """cov_mats: this rank's (p x L_g) matrices; global_ids: their positions in the whole data set (for the
-        partition-invariant down-sampling offsets); n_total: genes over all ranks."""
+        partition-invariant down-sampling offsets); n_total: genes over all ranks; n_threads: host packing threads
+        (0: as many as the box has, at most 16)."""
         if len(cov_mats) > 0:
             self.dev.hint_downsample(self.downsample_rate)
-            self.dev.upload(cov_mats)
+            self.dev.upload(cov_mats, n_threads=n_threads)
             if getattr(self.dev, 'inexact', 0):
                 logging.warning('{0} coverage values are not exactly representable in float32; they were rounded '
                                 'on upload.'.format(self.dev.inexact))
@@ -245,7 +248,7 @@ class ShardedNMFOA(object):
             n_bad_local = float(np.sum(status != 0))
         n_bad = _allreduce(self.comm, [n_bad_local])[0]
         if n_bad > 0:                                                 # every rank raises together
-            raise ValueError('rank-1 SVD failed on {0} gene(s) during initialisation (all-zero coverage?)'.format(int(n_bad)))
+            raise ValueError(self._init_failure_text(int(n_bad), n_bad_local, None if on_device else status))
         if not on_device:
             self.rho = 1 - (cov_sums / (est_sums + 1))
             low = self.rho.max(axis=1) < 0.1 if self.n_local > 0 else np.zeros(0, dtype=bool)
@@ -268,10 +271,34 @@ class ShardedNMFOA(object):
                 self.dev.outer_begin(self.x_weighted, max(1, self.degnorm_iter))
         self._state_on_device = False
         self.kernel_ms, self.traces, self.class_ms, self.span_ms = [], [], [], []
-        self.n_failed = []
+        self.n_failed, self.n_flagged = [], []
         self.scale_hist, self.rho_raw_hist, self.flags_hist = [], [], []     # per outer iteration: inputs / raw device outputs
         self.offsets_hist = []
         return self.scale_factors
+
+    def _init_failure_text(self, n_bad, n_bad_local, status):
+        """What ARPACK would have raised on: count over all ranks, and this rank's first such gene by name."""
+        first, noconv = '', False
+        if n_bad_local > 0:
+            if status is None:                                        # error path only: the statuses were left on the device
+                status = self.dev.init_status()
+            k = int(np.argmax(status != 0))
+            noconv = bool(np.any(status == -4))
+            if noconv:
+                k = int(np.argmax(status == -4))
+            first = ': first {0}'.format(self.gene_names[k] if self.gene_names is not None else 'local gene {0}'.format(k))
+        if noconv:
+            return ('the rank-1 SVD did not converge within the step cap on {0} gene(s) during initialisation '
+                    '(ARPACK would raise ArpackNoConvergence){1}'.format(n_bad, first))
+        return 'rank-1 SVD failed on {0} gene(s) during initialisation (all-zero coverage?){1}'.format(n_bad, first)
+
+    def _warn_unconverged(self, i, trace):
+        noconv = np.flatnonzero(trace[:, 6] == -4) if trace is not None and len(trace) else np.zeros(0, dtype=int)
+        if noconv.size:
+            names = [self.gene_names[k] if self.gene_names is not None else 'local gene {0}'.format(k) for k in noconv[:10]]
+            logging.warning('DegNorm iteration {0} -- the rank-1 SVD did not converge within the step cap on {1} gene(s) '
+                            '(ARPACK would raise ArpackNoConvergence); not used, DI left at 0: {2}{3}'
+                            .format(i + 1, noconv.size, ', '.join(names), ' ...' if noconv.size > 10 else ''))
 
     def _offsets(self, i):
         """
@@ -303,6 +330,7 @@ class ShardedNMFOA(object):
             self.kernel_ms.append(0.0)
             self.class_ms.append((0.0, 0.0, 0.0))
         self.traces.append(trace)
+        self._warn_unconverged(i, trace)
         self.scale_hist.append(np.copy(self.scale_factors))
         if self.history_rows is not None:                             # raw device outputs of a few genes (bench.py's parity check)
             self.rho_raw_hist.append(np.copy(rho[self.history_rows]))
@@ -319,7 +347,7 @@ class ShardedNMFOA(object):
         Wl = xw.sum(axis=0)
         n_fail = float(np.sum(trace[:, 6] != 0)) if trace is not None else 0.0
         n_noconv = float(np.sum(trace[:, 6] == -4)) if trace is not None else 0.0
-        avg_di, norm = self._reduce_and_update(i, np.concatenate([A, B, Wl, [float(untouched.sum()), n_fail, n_noconv]]))
+        avg_di, norm = self._reduce_and_update(i, np.concatenate([A, B, Wl, [float(untouched.sum()), n_fail, n_noconv, float(np.sum(flags))]]))
         if avg_di is not None:
             rho[untouched, :] = avg_di
         self.rho = rho
@@ -337,12 +365,13 @@ class ShardedNMFOA(object):
         """
         The per-sample all-reduce of an outer iteration and what every rank derives from it identically
         (nmf.py:148-158, :575-590): returns (avg_di or None, norm factors) and advances the scale factors.
-        partials = [A (p), B (p), W (p), #untouched, #failed genes, #unconverged genes] of this rank.
+        partials = [A (p), B (p), W (p), #untouched, #failed genes, #unconverged genes, #flagged genes] of this rank.
         """
         p = self.p
         tot = _allreduce(self.comm, partials)
         A, B, Wt, n_untouched = tot[:p], tot[p:2 * p], tot[2 * p:3 * p], tot[3 * p]
         self.n_failed.append((int(tot[3 * p + 1]), int(tot[3 * p + 2])))
+        self.n_flagged.append(int(tot[3 * p + 3]))                    # ran_baseline_selection[:, i].sum() (nmf.py:571)
         if tot[3 * p + 1] > 0:                                        # the same warning on every rank
             logging.warning('DegNorm iteration {0} -- {1} gene(s) hit a degenerate factorization (the reference would '
                             'raise), {2} of them an eigen-solve that did not converge; their DI scores were left at 0.'
@@ -366,6 +395,7 @@ class ShardedNMFOA(object):
             want_estimates=want_estimates, ds_start=ds, fetch=False)
         self._record_kernel_times()
         self.traces.append(trace)
+        self._warn_unconverged(i, trace)
         self.scale_hist.append(np.copy(self.scale_factors))
         if self.history_rows is not None:
             rho_rows, flag_rows = self.dev.fetch_rows(self.history_rows)
@@ -446,6 +476,10 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
                 raise ValueError('Not all coverage matrices are 2-d arrays!')
             li_vec = np.array([z.shape[1] for z in cov_dat.values()])
             p = int(next(iter(cov_dat.values())).shape[0])
+            if not all(z.shape[0] == p for z in cov_dat.values()):
+                raise ValueError('coverage matrices disagree on the number of samples')
+            if x.ndim != 2 or x.shape[1] != p:
+                raise ValueError('read count matrix must be (number of genes) x (number of samples)')
             if abs(int(downsample_rate)) > 1 and not np.min(li_vec) >= abs(int(downsample_rate)):
                 raise ValueError('downsample_rate is too large; take-every size > at least one gene.')
             if partition == 'contiguous':
@@ -456,8 +490,8 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
                 raise ValueError("partition must be 'balanced' or 'contiguous'")
             while len(parts) < size:                                      # fewer chunks than ranks: idle ranks get nothing
                 parts.append([])
-        except ValueError as e:
-            err = str(e)
+        except Exception as e:                                            # ANY failure of the checks reaches every rank: nobody waits in a receive
+            err = str(e) if isinstance(e, ValueError) else '{0}: {1}'.format(type(e).__name__, e)
     err, n_genes, p = _bcast(comm, (err, n_genes, p))
     if err is not None:
         raise ValueError(err)

@@ -27,6 +27,51 @@ def partition_by_length(lengths, n):
     return [sorted(q) for q in parts]
 
 
+def predicted_gene_cost(lengths, p=10, downsample_rate=1):
+    """
+    Relative cost of one outer iteration of a gene, from its length alone (known before anything is uploaded): the number of
+    active columns (L, or ceil(L / rate) when down-sampling) plus the fixed part every inner iteration pays (reduction +
+    eigen-solve), expressed in columns -- the constants are the measured per-column / per-iteration cycle counts of the
+    class the gene will run in (~700-1 200 cycles per column per lane of 64-256 lanes, ~5 800 per inner
+    iteration).  Only ratios matter.  Genes of the down-sampled regime cost the same fixed part each.
+    """
+    L = np.asarray(lengths, dtype=np.float64)
+    if downsample_rate > 1:
+        return np.ceil(L / float(downsample_rate)) + 64.0
+    lanes = np.where(L > 3819, 256.0, np.where(L > 1875, 128.0, 64.0))       # wide / narrow / pair class (p = 10 boundaries)
+    per_col = np.where(L > 3819, 1.25, 1.0)                                  # the wide class spills: ~25 % more per column
+    # columns per lane x cost per column + fixed part worth ~6 columns per lane, times the SIMDs the gene occupies
+    return (L / lanes * per_col + 6.0) * (lanes / 64.0)
+
+
+def partition_by_cost(lengths, n, p=10, downsample_rate=1):
+    """
+    Gene partition for the sharded run balanced on PREDICTED COST (predicted_gene_cost) instead of on length: genes are
+    taken most expensive first and each goes to the part with the least cost so far (LPT), ties to the part with fewer genes
+    of the gene's class, so that every GPU also gets the same share of every gene class (each class is its own kernel and
+    queue on a GPU).  Inside a part the original gene order is kept; always returns n lists.  Per-gene results do not depend
+    on the partition; the reference shards contiguous equal-count chunks (nmf_mpi.py:605).
+    """
+    n = int(n)
+    L = np.asarray(lengths, dtype=np.int64)
+    cost = predicted_gene_cost(L, p, downsample_rate)
+    cls = np.where(L > 3819, 0, np.where(L > 1875, 1, 2))
+    order = np.lexsort((np.arange(len(L)), -cost))                           # most expensive first, stable
+    parts = [[] for _ in range(n)]
+    load = np.zeros(n)
+    ncls = np.zeros((n, 3), dtype=np.int64)
+    for g in order:
+        c = cls[g]
+        # least loaded part; among near-equal loads (within one gene's cost) the one with the fewest genes of this class
+        lo = load.min()
+        cand = np.flatnonzero(load <= lo + 0.5 * cost[g])
+        r = int(cand[np.argmin(ncls[cand, c])])
+        parts[r].append(int(g))
+        load[r] += cost[g]
+        ncls[r, c] += 1
+    return [sorted(q) for q in parts]
+
+
 def chunk_bounds(length, n):
     """Start offsets (plus the end) of split_into_chunks(range(length), n)."""
     if length <= 0:

@@ -69,24 +69,47 @@ def write_sidecars(degnorm_dir, chroms=None):
     return out
 
 
+def _read_sidecar(pkl_file, npy_file, idx_file):
+    """
+    float32 views of the memory-mapped side-car, or None (with a log line) when it cannot be trusted: made from another
+    pickle (size / mtime), an index that does not describe the data file (p * sum(lengths) values, one length per gene), or
+    anything unreadable -- the caller then falls back to the pickle.
+    """
+    try:
+        with np.load(idx_file) as idx:
+            genes, lengths = idx['genes'].tolist(), idx['lengths'].astype(np.int64)
+            p, inexact = int(idx['p']), int(idx['inexact'])
+            pkl_size, pkl_mtime_ns = int(idx['pkl_size']), int(idx['pkl_mtime_ns'])
+        st = os.stat(pkl_file)
+        if pkl_size != st.st_size or pkl_mtime_ns != st.st_mtime_ns:
+            logging.info('{0} is stale (the pickle changed): ignored.'.format(npy_file))
+            return None
+        packed = np.load(npy_file, mmap_mode='r')
+        if (packed.dtype != np.float32 or packed.ndim != 1 or len(genes) != len(lengths) or p < 1
+                or np.any(lengths < 1) or packed.size != p * int(lengths.sum())):
+            logging.warning('{0} does not match its index ({1} values for p = {2}, {3} genes): ignored.'
+                            .format(npy_file, packed.size, p, len(genes)))
+            return None
+    except Exception as e:                                     # truncated / foreign files: the pickle is the source of truth
+        logging.warning('{0} could not be read ({1}): ignored.'.format(npy_file, e))
+        return None
+    if inexact:
+        logging.warning('{0}: {1} coverage values are not exactly representable in float32.'.format(npy_file, inexact))
+    out, o = OrderedDict(), 0
+    for g, L in zip(genes, lengths.tolist()):
+        out[g] = packed[o:o + p * L].reshape(p, L)
+        o += p * L
+    return out
+
+
 def _load_chrom(degnorm_dir, chrom, use_sidecar):
     """{gene: p x L matrix} of one chromosome: float32 views into the memory-mapped side-car when it is present and was
     made from the pickle that is there now, else the unpickled float64 dict."""
     pkl_file, npy_file, idx_file = _sidecar_paths(degnorm_dir, chrom)
     if use_sidecar and os.path.isfile(npy_file) and os.path.isfile(idx_file):
-        idx = np.load(idx_file)
-        st = os.stat(pkl_file)
-        if int(idx['pkl_size']) == st.st_size and int(idx['pkl_mtime_ns']) == st.st_mtime_ns:
-            if int(idx['inexact']):
-                logging.warning('{0}: {1} coverage values are not exactly representable in float32.'.format(npy_file, int(idx['inexact'])))
-            packed = np.load(npy_file, mmap_mode='r')
-            p = int(idx['p'])
-            out, o = OrderedDict(), 0
-            for g, L in zip(idx['genes'].tolist(), idx['lengths'].tolist()):
-                out[g] = packed[o:o + p * L].reshape(p, L)
-                o += p * L
+        out = _read_sidecar(pkl_file, npy_file, idx_file)
+        if out is not None:
             return out
-        logging.info('{0} is stale (the pickle changed): ignored.'.format(npy_file))
     with open(pkl_file, 'rb') as f:
         return pkl.load(f)
 

@@ -105,11 +105,13 @@ int  dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *pr
  * Replaces: the O(n p) host arithmetic between two baseline-selection sweeps -- the DI clip (nmf.py:398-399),
  * correct_di_scores (:148-158), x_adj (:575, :581), the normalisation of the weighted counts (:584-587) and the
  * ran_baseline_selection column (:403); nmf_mpi.py:821-838 on rank 0.  With it dn_baseline_iteration may be called with
- * rho = flags = NULL: the n x p DI matrix stays in HBM and the host sees 3p + 3 numbers per iteration.
+ * rho = flags = NULL: the n x p DI matrix stays in HBM and the host sees 3p + 4 numbers per iteration.
  *   dn_outer_begin     x_weighted (n x p, after the initial normalisation, nmf.py:534) -> device; degnorm_iter columns of flags
  *   dn_outer_partials  after dn_baseline_iteration: partials[0:p] = sum over touched genes of x_w / (1 - rho),
  *                      [p:2p] = sum over untouched genes (rho.max() == 0) of x_w, [2p:3p] = sum of x_w,
- *                      [3p] = #untouched, [3p+1] = #genes with trace status != 0, [3p+2] = #genes with status -4
+ *                      [3p] = #untouched, [3p+1] = #genes with trace status != 0, [3p+2] = #genes with status -4,
+ *                      [3p+3] = #genes sent through baseline selection (ran_baseline_selection[:, iter].sum(), nmf.py:571)
+ *                      -- 3p + 4 doubles
  *                      (sums in a fixed order; the caller all-reduces them over the GPUs)
  *   dn_outer_apply     rho[untouched] = avg_di (NULL: none untouched); x_adj = x_w / (1 - rho); x_w /= norm; flags -> column iter
  *   dn_fetch_outer     final rho / x_adj / x_weighted (n x p each) and ran_baseline_selection (n x degnorm_iter bytes); any may be NULL
@@ -122,7 +124,7 @@ int  dn_outer_begin(dn_handle h, const double *x_weighted, int32_t degnorm_iter)
  *   dn_init_begin          reads (n x p float64 read counts) -> device, once per upload
  *   dn_ratio_svd_sums      may then be called with est_sums = cov_sums = NULL (the sums stay in HBM)
  *   dn_init_partials       partials[0:p] = sum over the low genes of x, [p:2p] = sum over all genes of x, [3p] = #low genes,
- *                          [3p+1] = #genes whose initial SVD failed ([2p:3p], [3p+2] unused); fixed order, for the all-reduce
+ *                          [3p+1] = #genes whose initial SVD failed ([2p:3p], [3p+2], [3p+3] unused; 3p + 4 doubles); fixed order, for the all-reduce
  *   dn_outer_begin_scaled  dn_outer_begin with x_weighted = reads / norm formed on the device                        */
 int  dn_init_begin(dn_handle h, const double *reads);
 int  dn_init_partials(dn_handle h, double *partials);

@@ -196,6 +196,17 @@ def test_input_errors_are_raised_on_every_rank(oracle_device):
     assert all(isinstance(e, ValueError) and 'downsample_rate is too large' in str(e) for e in errs)
     out, errs = _run_threads(3, cov_dat, G['reads'][:-1], degnorm_iter=1, nmf_iter=10)
     assert all(isinstance(e, ValueError) and 'Number of genes in read count matrix' in str(e) for e in errs)
+    # a gene with another sample count, a read matrix with the wrong width, a 1-d read vector: on EVERY rank, nobody hangs
+    from collections import OrderedDict
+    odd = OrderedDict(cov_dat)
+    first = next(iter(odd))
+    odd[first] = odd[first][:-1]
+    out, errs = _run_threads(3, odd, G['reads'], degnorm_iter=1, nmf_iter=10)
+    assert all(isinstance(e, ValueError) and 'disagree on the number of samples' in str(e) for e in errs)
+    out, errs = _run_threads(3, cov_dat, G['reads'][:, :-1], degnorm_iter=1, nmf_iter=10)
+    assert all(isinstance(e, ValueError) and 'read count matrix must be' in str(e) for e in errs)
+    out, errs = _run_threads(3, cov_dat, np.ones(len(cov_dat)), degnorm_iter=1, nmf_iter=10)
+    assert all(isinstance(e, ValueError) for e in errs) and len(errs) == 3
 
 
 def test_downsampled_run_is_partition_invariant(oracle_device):

@@ -105,6 +105,17 @@ def test_sidecar_gives_the_same_inputs_and_goes_stale(tmp_path):
     assert again['gene_cov_dict'][first].dtype == np.float64 and np.array_equal(again['gene_cov_dict'][first], d[first])
     other = next(g for g in again['gene_cov_dict'] if g not in d)          # another chromosome still comes from its side-car
     assert again['gene_cov_dict'][other].dtype == np.float32
+    # a truncated / foreign data file that still passes the stat check of its index: fall back to the pickle, do not crash
+    npy = os.path.join(src, 'chr2', 'coverage_matrices_chr2.f32.npy')
+    full = np.load(npy)
+    np.save(npy, full[:-7])
+    again = load_from_previous(src)
+    chr2 = [g for g in ref['gene_cov_dict'] if g in again['gene_cov_dict'] and again['gene_cov_dict'][g].dtype == np.float64 and g not in d]
+    assert chr2 and all(np.array_equal(again['gene_cov_dict'][g], ref['gene_cov_dict'][g]) for g in chr2)
+    with open(npy, 'wb') as f:
+        f.write(b'not a numpy file')
+    again = load_from_previous(src)
+    assert all(np.array_equal(again['gene_cov_dict'][g], ref['gene_cov_dict'][g]) for g in chr2)
 
 
 def _sharded_warm_start(tmp_path, G, size, use_sidecar):
