@@ -179,7 +179,18 @@ def pmc_traffic(config, kernel_name, genes_in_kernel):
     return float(k['hbm_bytes_per_launch']), info
 
 
+_HOST_CORES = None
+
+
 def host_cores():
+    """Threads the oracle may use on this box; asked once (a later single-thread oracle run lowers OpenMP's own maximum)."""
+    global _HOST_CORES
+    if _HOST_CORES is None:
+        _HOST_CORES = _host_cores()
+    return _HOST_CORES
+
+
+def _host_cores():
     from oracle import oracle as orc
     cores = int(orc.lib().dno_max_threads())
     try:
@@ -574,6 +585,9 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
                         'counts 8 p L_g per gene and outer iteration = {0:.3e} B per launch'.format(alg_init),
             'note': 'rank-0 shard; HIP events on the library stream'}
     out['setup'] = {'synth_s': t_gen, 'upload_s': t_up}
+    if args.dump_traces:                                                # per-gene counters of the last step (tools/partition_study.py)
+        np.savez_compressed(args.dump_traces + '.' + config, lengths=lengths, gene_ids=np.asarray(my_genes),
+                            traces=np.stack([tr[:, :8] for tr in eng.traces]), class_ms=np.asarray(eng.class_ms))
     out['parity'] = parity_check(eng, pick, cfg, p, my_genes, lengths, split, args.nmf_iter, rate) if pick is not None else None
     final_scale = np.copy(eng.scale_factors)
     try:
@@ -626,6 +640,12 @@ def run_rank(args):
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     args.gpus = world
 
+    # stdout carries ONE JSON line: libraries that print there (RCCL's version banner at communicator creation) are sent to
+    # stderr for the life of the rank; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from degnorm_amd.nmf_mpi import TorchComm, LocalComm
@@ -670,11 +690,12 @@ def run_rank(args):
         sub = measure('c4', args, ctx, 3, 2, args.parity_genes, 2048 if n_cpu > 0 else 0, 512 if n_single > 0 else 0, False)
         out['also'] = {'config 4': {k: sub[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline',
                                                         'parity', 'cpu_baseline', 'setup')}}
-    if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
     if pg is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(result_fd, (json.dumps(out) + '\n').encode())
+    os.close(result_fd)
 
 
 def parse(argv=None):
@@ -692,6 +713,7 @@ def parse(argv=None):
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the GeneNMFOA.fit() end-to-end timing (config 2, N = 1)')
     ap.add_argument('--no-also', action='store_true', help='skip the config-4 measurement appended to the default config-2 line')
     ap.add_argument('--no-rccl', action='store_true', help='N = 1 without torchrun: do not open a one-rank RCCL process group')
+    ap.add_argument('--dump-traces', default='', help='write the per-gene device counters of the last step to FILE.<config>.npz')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='collective backend of the ranks: nccl = RCCL (the measured path); gloo only to rehearse N > 1 on ONE GPU '
                          '(every rank on device 0; the line is then marked "rehearsal")')
