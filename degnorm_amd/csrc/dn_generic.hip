@@ -30,8 +30,9 @@
 #elif DN_GEN_NT == 64
 #define DN_GEN_NS gen_rows
 #ifndef DN_GEN_MINW
-#define DN_GEN_MINW 4           // <= 128 registers: four waves per SIMD
-#endif
+#define DN_GEN_MINW 3           // <= 168 registers, three waves per SIMD: the loop of nmf_rows is bound by instruction issue, not by
+#endif                          // latency, and at 128 registers (four waves) its Gram products spill (config 4 sweep 6.4 -> 4.8 ms with
+                                // the per-column-count instantiations; four waves: 4.9)
 #else
 #error "DN_GEN_NT must be 256 or 64"
 #endif
@@ -193,9 +194,12 @@ __device__ __attribute__((noinline)) void nmf_gen(const float *Fb, double *A, do
 // K E = (A v) v^T, so u_s sigma = a_s . v.  Same outputs as nmf_gen.  The other waves of the workgroup wait.
 // ---------------------------------------------------------------------------------------------------
 constexpr int NSM_MAX = 12;                   // widest active matrix the row-wise routine takes
+#ifndef DN_ROWS_EXACT
+#define DN_ROWS_EXACT 1         // one instantiation of nmf_rows per column count 2..12 (0: capacities 4 / 6 / 8 / 10 / 12)
+#endif
 constexpr int ROWS_ZSLOT = 255;               // last double of g_rows_tot, kept at 0.0 (padding lanes of the solver read it)
 
-// NSM: compiled column capacity (4, 8 or 12: the Gram matrix and the solver's tile shrink with it)
+// NSM: compiled column capacity (4, 6, 8, 10 or 12: the Gram matrix and the solver's tile shrink with it)
 template <int NSM>
 __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, double *sv, double *sj,
                                                    int n, int S, int T, int first_i, int p)
@@ -407,9 +411,27 @@ __global__ __launch_bounds__(NT, DN_GEN_MINW) void k_baseline_gen(IterArgs A)
                 int csize = 1, n_bins = 0;
                 bool first = true, in_loop = false;
                 for (;;) {
+                    // one instantiation per column count (DN_ROWS_EXACT) or per even capacity: the n x n Gram matrix has
+                    // NSM (NSM + 1) / 2 entries to multiply and reduce-scatter over the lanes every inner iteration (the
+                    // bulk of the loop's ~1 000 instructions; at most 64 entries go in ONE round) and the solver
+                    // ceil(NSM / 4) MFMAs per product -- config 4's first calls have 9-10 columns
+#if DN_ROWS_EXACT
+#define DN_ROWS_CASE(N) case N: nmf_rows<N>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p); break;
+                    if (n <= NSM_MAX) {
+                        switch (n) {
+                            DN_ROWS_CASE(3) DN_ROWS_CASE(4) DN_ROWS_CASE(5) DN_ROWS_CASE(6) DN_ROWS_CASE(7) DN_ROWS_CASE(8)
+                            DN_ROWS_CASE(9) DN_ROWS_CASE(10) DN_ROWS_CASE(11) DN_ROWS_CASE(12)
+                            default: nmf_rows<2>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p); break;
+                        }
+                    }
+#undef DN_ROWS_CASE
+#else
                     if (n <= 4) nmf_rows<4>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    else if (n <= 6) nmf_rows<6>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
                     else if (n <= 8) nmf_rows<8>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    else if (n <= 10) nmf_rows<10>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
                     else if (n <= NSM_MAX) nmf_rows<12>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+#endif
                     else nmf_gen(Fb, Ast, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
                     if (g_st.status != ST_OK) { status = g_st.status; break; }
                     n_calls++; sum_cols += n;
