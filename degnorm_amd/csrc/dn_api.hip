@@ -780,7 +780,11 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     a.est_sums = h->d_est_sums; a.cov_sums = h->d_cov_sums; a.status = h->d_status; a.n_genes = (int32_t) h->n;
     a.p = h->p; a.ws = h->d_ws; a.slot_bytes = h->slot_bytes; a.S = h->S; a.max_steps = h->max_steps;
     HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * 4, h->stream));
-    int per_cu = std::max(1, h->ks->blocks_per_cu(1));
+    // occupancy of the kernel that ks->init() will start: from 17 samples on it is the matrix-core variant (round 2 asked for
+    // the power-iteration kernel's figure here and ran k_ratio_svd_mg at ONE workgroup per CU instead of two)
+    const char *pw = getenv("DN_INIT_POWER");
+    const int which_init = (h->p >= 17 && !(pw && pw[0] == '1')) ? 2 : 1;
+    int per_cu = std::max(1, h->ks->blocks_per_cu(which_init));
     int grid = (int) std::min<int64_t>(h->n, (int64_t) per_cu * h->n_cus);
     if (h->ks->p == 0) grid = std::min(grid, h->slots);          // generic kernels work in the scratch slots
     HIP_TRY(hipEventRecord(h->ev_i0, h->stream));

@@ -648,11 +648,10 @@ __device__ __forceinline__ int top_singular_raw(const float *x, int L, int p)
 //           and the B operand.  Row p of the padded matrix is a row of ones, so that G[p][i] = sum_j x_ij: the plain
 //           row sums (cov_sums) fall out of the same products.  Waves take 16-column groups round-robin; their tiles are
 //           added in LDS one wave after the other (fixed order: deterministic).
-//   solve   top eigenvector of the p x p block by shifted power iteration, the matrix in LDS, all 256 threads on one
-//           matrix-vector product (thread = (row, quarter of the columns)), two steps between convergence checks, the
-//           same stopping rule as top_eig_rows.
+//   solve   top eigenvector of the p x p block by shifted power iteration, the matrix in LDS, ONE wave (lane = row, no barrier
+//           inside the iteration), two steps between convergence checks, the same stopping rule as top_eig_rows.
 //   pass 2  one column per lane: s_j = u . x_j from the p counts of the column (registers), per-lane partial sums of
-//           max(u_i s_j, x_ij) for every row, reduced at the end in tiles of 8.
+//           max(u_i s_j, x_ij) for every row kept in registers for the whole gene, reduced once at the end.
 // ---------------------------------------------------------------------------------------------------
 constexpr int MG_ROWS = 80;                  // 5 tiles of 16: p <= 64 samples + the row of ones
 constexpr int MG_LD = MG_ROWS + 1;           // LDS row stride in doubles (odd: the column walk of the solver is conflict-light)
@@ -748,92 +747,159 @@ __device__ __forceinline__ void mg_gram_pass(const float *x, int L, int p)
                     for (int r = 0; r < 4; r++) {
                         const int row = 16 * t1 + lk + 4 * r, col = 16 * t2 + li;
                         const double v = acc[tix][r];
-                        if (ww == 0) {
-                            g_mg[row * MG_LD + col] = v;
-                            if (t1 != t2) g_mg[col * MG_LD + row] = v;
-                        } else {
-                            g_mg[row * MG_LD + col] += v;
-                            if (t1 != t2) g_mg[col * MG_LD + row] += v;
-                        }
+                        if (ww == 0) g_mg[row * MG_LD + col] = v;
+                        else g_mg[row * MG_LD + col] += v;
                     }
         }
         __syncthreads();
     }
-}
-
-// y = (G - mu I) v for the p x p block of g_mg; v in g_mv[src], y to g_mv[dst] and returned for this thread's row.
-__device__ __forceinline__ double mg_matvec(int p, int src, int dst, double mu)
-{
-    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-    double part = 0.0;
-    if (r < p) {
-        const double *row = g_mg + r * MG_LD;
-        for (int j = q; j < p; j += 4) part = fma(row[j], g_mv[src][j], part);
+    // the tiles below the diagonal were accumulated once; their mirror images are copied now (the solver walks whole rows)
+    constexpr int R = 16 * TR;
+    for (int idx = threadIdx.x; idx < R * R; idx += NT) {
+        const int r = idx / R, c = idx - r * R;
+        if ((c >> 4) > (r >> 4)) g_mg[r * MG_LD + c] = g_mg[c * MG_LD + r];
     }
-    part += dpp_mov<DPP_QX1>(part);
-    part += dpp_mov<DPP_QX2>(part);
-    const double y = (r < p) ? fma(-mu, g_mv[src][r], part) : 0.0;
-    __syncthreads();                                   // every reader of g_mv[dst]'s previous contents is done
-    if (q == 0 && r < MG_ROWS) g_mv[dst][r] = y;
     __syncthreads();
-    return y;
 }
 
-// block-wide sum of one value per (row) thread group; only threads with q == 0 contribute
-__device__ __forceinline__ double mg_block_sum(double v)
-{
-    double part[TI];
-    part[0] = (threadIdx.x & 3) == 0 ? v : 0.0;
-#pragma unroll
-    for (int r = 1; r < TI; r++) part[r] = 0.0;
-    tile_sum(part);
-    const double s = g_sm.tot[0];
-    __syncthreads();
-    return s;
-}
-
+// Top eigenvector of the p x p block of g_mg (p <= 64) by ONE wave: lane r keeps to row r of the matrix in LDS (row stride
+// MG_LD = 81 doubles: the 64 lanes hit different banks), the vectors live in g_mv and are read with broadcast loads, norms and
+// the Rayleigh quotient are all-reduced over the lanes in registers -- no barrier inside the iteration (the block-wide form
+// this replaces paid two barriers per matrix-vector product plus two block reductions per check: 53 k cycles per gene for 7
+// steps).  Shifted power iteration, two plain steps between convergence checks, the stopping rule of top_eig_rows.  The other
+// waves wait at the closing barrier; with two workgroups per CU their SIMDs run the neighbour's passes meanwhile.
 __device__ __forceinline__ int mg_solve(int p, int maxs, double *u_out)
 {
-    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-    // trace and the first product from the uniform start vector
-    if (q == 0 && r < MG_ROWS) g_mv[0][r] = r < p ? 1.0 / sqrt((double) p) : 0.0;
-    __syncthreads();
-    const double tr = mg_block_sum(r < p ? g_mg[r * MG_LD + r] : 0.0);
-    if (!(tr > 0.0)) return ST_ARPACK;
-    double ul = r < p ? g_mv[0][r] : 0.0;
-    double y = mg_matvec(p, 0, 1, 0.0);
-    const double th = mg_block_sum(ul * y);
-    if (!(th > 0.0)) return ST_ARPACK;
-    double mu = (tr - th) / (double) (p > 1 ? p - 1 : 1);
-    mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
-    double vl = fma(-mu, ul, y);                       // first shifted step, in g_mv[1] unshifted: rewrite it
-    __syncthreads();
-    if (q == 0 && r < MG_ROWS) g_mv[1][r] = vl;
-    __syncthreads();
-    int steps = 1, status = ST_OK;
-    double d2_prev = -1.0;
-    for (;;) {
-        // normalise the iterate in g_mv[1] into g_mv[0], measure the change
-        const double n2 = mg_block_sum(vl * vl);
-        if (!(n2 > 0.0)) { status = ST_ARPACK; break; }
-        const double inv = 1.0 / sqrt(n2);
-        const double un = vl * inv;
-        const double d = un - ul;
-        const double d2 = mg_block_sum(d * d);
-        ul = un;
-        if (q == 0 && r < MG_ROWS) g_mv[0][r] = ul;
-        __syncthreads();
-        if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev)) break;
-        if (steps >= maxs) { status = ST_NO_CONVERGENCE; break; }
-        d2_prev = d2;
-        (void) mg_matvec(p, 0, 1, mu);                 // two plain shifted steps, no normalisation in between
-        vl = mg_matvec(p, 1, 1, mu);
-        steps += 2;
+    int status = ST_OK;
+    if (wave_id() == 0) {
+        const int lane = lane_id();
+        const bool live = lane < p;
+        const int r = live ? lane : p - 1;
+        const double *Gr = g_mg + r * MG_LD;
+        double *uv = g_mv[0], *vv = g_mv[1];
+        // entries p .. 63 of the vectors are 0 and the matrix has 16 TR >= p rows / columns of finite numbers: the products run
+        // over whole groups of 8 columns, eight LDS reads in flight and four independent sums
+        const int p8 = (p + 7) & ~7;
+        auto row_dot = [&](const double *vec) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma clang loop unroll(disable)
+            for (int j = 0; j < p8; j += 8) {
+                double gq[8], vq[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { gq[k] = Gr[j + k]; vq[k] = vec[j + k]; }
+                a0 = fma(gq[0], vq[0], a0); a1 = fma(gq[1], vq[1], a1); a2 = fma(gq[2], vq[2], a2); a3 = fma(gq[3], vq[3], a3);
+                a0 = fma(gq[4], vq[4], a0); a1 = fma(gq[5], vq[5], a1); a2 = fma(gq[6], vq[6], a2); a3 = fma(gq[7], vq[7], a3);
+            }
+            return live ? (a0 + a1) + (a2 + a3) : 0.0;
+        };
+        const double tr = wave_allsum(live ? Gr[r] : 0.0);
+        double ul = live ? 1.0 / sqrt((double) p) : 0.0;
+        uv[lane] = ul; vv[lane] = 0.0;                                  // lanes >= p hold 0 (MG_ROWS >= 64 entries)
+        wave_fence();
+        int steps = 1;
+        if (!(tr > 0.0)) status = ST_ARPACK;
+        else {
+            double y = row_dot(uv);                                     // (G u)_l
+            const double th = wave_allsum(ul * y);
+            if (!(th > 0.0)) status = ST_ARPACK;
+            else {
+                double mu = (tr - th) / (double) (p > 1 ? p - 1 : 1);
+                mu = (mu > 0.0 && mu < 0.5 * th) ? mu : 0.0;
+                double vl = fma(-mu, ul, y);                            // first shifted step
+                double d2_prev = -1.0;
+                for (;;) {
+                    const double n2 = wave_allsum(vl * vl);
+                    if (!(n2 > 0.0)) { status = ST_ARPACK; break; }
+                    const double inv = 1.0 / sqrt(n2);
+                    const double un = vl * inv;
+                    const double d = un - ul;
+                    const double d2 = wave_allsum(d * d);
+                    ul = un;
+                    wave_fence();
+                    uv[lane] = ul;
+                    wave_fence();
+                    if (d2 <= 1e-26 || (d2_prev > 0.0 && 4.0 * d2 < d2_prev && 4.0 * d2 * d2 <= 1e-26 * d2_prev)) break;
+                    if (steps >= maxs) { status = ST_NO_CONVERGENCE; break; }
+                    d2_prev = d2;
+                    const double wl = fma(-mu, ul, row_dot(uv));        // two plain shifted steps, no normalisation in between
+                    vv[lane] = wl;
+                    wave_fence();
+                    vl = fma(-mu, wl, row_dot(vv));
+                    wave_fence();
+                    steps += 2;
+                }
+            }
+        }
+        if (live) u_out[lane] = ul;
+        if (lane == 0) { g_st.steps = steps; g_st.status = status; }
     }
-    if (q == 0 && r < p) u_out[r] = ul;
-    if (tid == 0) g_st.steps = steps;
+    __syncthreads();
+    status = g_st.status;
     __syncthreads();
     return status;
+}
+
+// Pass 2 of the initial DI pass: a wave takes 64 columns at a time, lane = column.  The p counts of the column are loaded once
+// (p independent 256-byte row segments per wave in flight), s_j = u . x_j is formed from them, and every row keeps a per-lane
+// partial sum of max(u_i s_j, x_ij) in registers for the whole gene (RC doubles, RC = p rounded up to 8; with the column: 3 RC
+// registers, <= 192);
+// the block adds them up once per gene (register reduce-scatter per wave, 32 rows per round).  u is read from LDS with
+// broadcast loads.  One read of the gene instead of the two of the row-tiled form this replaces (s_j staged in LDS, rows
+// walked in tiles of 8: 27.5 GB more traffic on config 4).
+template <int RC>                                                    // row capacity of this instantiation (p <= RC), a multiple of 8
+__device__ __attribute__((noinline)) void mg_pass2(const float *x_, int L, int p)
+{
+    constexpr int W = NT / 64;
+    const int tid = threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
+    const float *x = uniform_ptr(x_);                                   // row bases stay in scalar registers: loads take saddr + lane offset
+    L = __builtin_amdgcn_readfirstlane(L);
+    p = __builtin_amdgcn_readfirstlane(p);
+    // rows p .. RC - 1 are walked like the others, without a branch: their u is 0 (no part in s_j), they re-read row p - 1
+    // (the line is in L2) and their sums are never looked at
+    if (tid >= p && tid < RC) g_st.u[tid] = 0.0;
+    __syncthreads();
+    double acc[RC];
+#pragma unroll
+    for (int i = 0; i < RC; i++) acc[i] = 0.0;
+    typedef const char __attribute__((address_space(1))) *gbyte_cptr;
+    const long long Lb = (long long) L * 4;                             // row pitch in bytes
+#pragma clang loop unroll(disable)
+    for (int k0 = 64 * w; k0 < L; k0 += 64 * W) {
+        const bool valid = k0 + lane < L;
+        const unsigned voff = 4u * (unsigned) (valid ? lane : L - 1 - k0);   // clamped: no branch around the loads
+        gbyte_cptr row = (gbyte_cptr) (x + k0);
+        float xv[RC];
+#pragma unroll
+        for (int i = 0; i < RC; i++) {
+            xv[i] = *(gF_cptr) (row + voff);                            // scalar base + 32-bit lane offset
+            row += (i + 1 < p) ? Lb : 0;
+            asm volatile("" : "+s"(row));                               // one running scalar base (else every row's address is formed on its own)
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < RC; i += 2) {
+            s0 = fma(g_st.u[i], (double) xv[i], s0);
+            s1 = fma(g_st.u[i + 1], (double) xv[i + 1], s1);
+        }
+        if (valid) {                                                    // lanes beyond the gene's end add nothing (one exec mask, no per-element select)
+            const double sj = s0 + s1;
+#pragma unroll
+            for (int i = 0; i < RC; i++) {
+                asm volatile("" : "+v"(xv[i]));                         // convert again here: keeping the RC doubles of the dot product alive spills them
+                acc[i] += fmax(g_st.u[i] * sj, (double) xv[i]);         // est[est < x] = x   nmf.py:119
+            }
+        }
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < RC; i0 += 32) {
+        constexpr int dummy = 0; (void) dummy;
+        double part[32];
+#pragma unroll
+        for (int r = 0; r < 32; r++) part[r] = i0 + r < RC ? acc[i0 + r < RC ? i0 + r : 0] : 0.0;
+        block_sum_lds<32, DN_P, NT, double>(part, g_sm);
+        if (tid < 32 && i0 + tid < p) g_st.csum[i0 + tid] = g_sm.tot[tid];
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(NT, 2) void k_ratio_svd_mg(InitArgs A)
@@ -852,92 +918,48 @@ __global__ __launch_bounds__(NT, 2) void k_ratio_svd_mg(InitArgs A)
         const int L = A.glen[g];
         const float *x = A.cov + A.goff[g];
         int status = ST_OK;
+#ifdef DN_STAMP
+        const long long ts0 = __builtin_amdgcn_s_memtime();
+        long long ts1 = ts0, ts2 = ts0;
+#endif
         if (L < 2) status = ST_VALUE_ERROR;
         else {
             if (TR <= 2) mg_gram_pass<2>(x, L, p);
             else if (TR == 3) mg_gram_pass<3>(x, L, p);
             else if (TR == 4) mg_gram_pass<4>(x, L, p);
             else mg_gram_pass<5>(x, L, p);
+#ifdef DN_STAMP
+            ts1 = __builtin_amdgcn_s_memtime();
+#endif
             status = mg_solve(p, maxs, g_st.u);
+#ifdef DN_STAMP
+            ts2 = __builtin_amdgcn_s_memtime();
+#endif
         }
-        // pass 2 (nmf.py:117-121, :524-525): est = max(K E, x) summed per row.  The Gram matrix is no longer needed: its
-        // row of ones (the plain row sums) moves to g_st.rsum, and g_mg holds s_j = u . x_j of a chunk of columns, so
-        // that the rows can be walked in tiles of 8 with 8 live accumulators instead of p.
+        // pass 2 (nmf.py:117-121, :524-525): est = max(K E, x) summed per row, in ONE more read of the gene.  The plain row
+        // sums come from the Gram matrix's row of ones.
         if (tid < p) { g_st.rsum[tid] = g_mg[p * MG_LD + tid]; g_st.csum[tid] = 0.0; }
         __syncthreads();
         if (status == ST_OK) {
-            constexpr int CHUNK = MG_ROWS * MG_LD;                                  // 6 480 columns of s per chunk
-            double *sj = g_mg;
-            for (int c0 = 0; c0 < L; c0 += CHUNK) {
-                const int c1 = (c0 + CHUNK < L) ? c0 + CHUNK : L;
-                // NC columns per thread and TI rows per step: NC * TI independent loads in flight (a dependent
-                // load -> fma chain over the p rows of one column would pay the memory latency p times)
-                constexpr int NC = 4;
-                for (int k = c0 + tid; k < c1; k += NC * NT) {
-                    int kc[NC];
-#pragma unroll
-                    for (int c = 0; c < NC; c++) kc[c] = (k + c * NT < c1) ? k + c * NT : k;        // clamped: no branch around the loads
-                    double sd[NC];
-#pragma unroll
-                    for (int c = 0; c < NC; c++) sd[c] = 0.0;
-                    for (int i0 = 0; i0 < p; i0 += TI) {
-                        float xv[NC][TI];
-#pragma unroll
-                        for (int r = 0; r < TI; r++) {
-                            const size_t ro = (size_t) (i0 + r < p ? i0 + r : p - 1) * L;
-#pragma unroll
-                            for (int c = 0; c < NC; c++) xv[c][r] = x[ro + kc[c]];
-                        }
-#pragma unroll
-                        for (int r = 0; r < TI; r++) {
-                            const double ur = i0 + r < p ? g_st.u[i0 + r] : 0.0;
-#pragma unroll
-                            for (int c = 0; c < NC; c++) sd[c] = fma(ur, (double) xv[c][r], sd[c]);
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < NC; c++) if (k + c * NT < c1) sj[k + c * NT - c0] = sd[c];
-                }
-                __syncthreads();
-                for (int i0 = 0; i0 < p; i0 += TI) {
-                    double part[TI];
-#pragma unroll
-                    for (int r = 0; r < TI; r++) part[r] = 0.0;
-                    for (int k = c0 + tid; k < c1; k += NC * NT) {
-                        int kc[NC];
-                        double sk[NC];
-#pragma unroll
-                        for (int c = 0; c < NC; c++) { kc[c] = (k + c * NT < c1) ? k + c * NT : k; sk[c] = sj[kc[c] - c0]; }
-                        float xv[NC][TI];
-#pragma unroll
-                        for (int r = 0; r < TI; r++) {
-                            const size_t ro = (size_t) (i0 + r < p ? i0 + r : p - 1) * L;
-#pragma unroll
-                            for (int c = 0; c < NC; c++) xv[c][r] = x[ro + kc[c]];
-                        }
-#pragma unroll
-                        for (int r = 0; r < TI; r++) {
-                            const double ur = g_st.u[i0 + r < p ? i0 + r : p - 1];
-#pragma unroll
-                            for (int c = 0; c < NC; c++) {
-                                const double v = (double) xv[c][r];
-                                const double ke = ur * sk[c];
-                                const double e = ke < v ? v : ke;                   // est[est < x] = x   nmf.py:119
-                                part[r] += (k + c * NT < c1) ? e : 0.0;
-                            }
-                        }
-                    }
-                    tile_sum(part);
-                    if (tid < TI && i0 + tid < p) g_st.csum[i0 + tid] += g_sm.tot[tid];
-                    __syncthreads();
-                }
-            }
+            if (p <= 24) mg_pass2<24>(x, L, p);
+            else if (p <= 32) mg_pass2<32>(x, L, p);
+            else if (p <= 40) mg_pass2<40>(x, L, p);
+            else if (p <= 48) mg_pass2<48>(x, L, p);
+            else if (p <= 56) mg_pass2<56>(x, L, p);
+            else mg_pass2<64>(x, L, p);
         }
         if (tid < p) {
             A.est_sums[(size_t) g * p + tid] = status == ST_OK ? g_st.csum[tid] : 0.0;
             A.cov_sums[(size_t) g * p + tid] = status == ST_OK ? g_st.rsum[tid] : 0.0;
         }
         if (tid == 0) A.status[g] = status;
+#ifdef DN_STAMP          // diagnostic build: the first four sums of the gene are REPLACED by cycles of pass 1 / solve / pass 2 and the solver's steps
+        if (tid == 0) {
+            const long long ts3 = __builtin_amdgcn_s_memtime();
+            A.est_sums[(size_t) g * p + 0] = (double) (ts1 - ts0); A.est_sums[(size_t) g * p + 1] = (double) (ts2 - ts1);
+            A.est_sums[(size_t) g * p + 2] = (double) (ts3 - ts2); A.est_sums[(size_t) g * p + 3] = (double) g_st.steps;
+        }
+#endif
         __syncthreads();
     }
 }
@@ -1064,7 +1086,10 @@ static void launch_init(const InitArgs &a, int grid, hipStream_t s)
 static int blocks_per_cu(int which)
 {
     int nb = 0;
+    // which: 0 the iteration kernel, 1 the initial pass by power iteration (p <= 16 here), 2 the initial pass with the Gram
+    // matrix on the matrix cores (k_ratio_svd_mg, 17 <= p <= 64: what launch_init starts for those sample counts)
     hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_baseline_gen, NT, 0)
+                 : which == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd_mg, NT, 0)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd_gen, NT, 0);
     return e == hipSuccess ? nb : 0;
 }

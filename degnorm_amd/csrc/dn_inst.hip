@@ -74,7 +74,7 @@ static int blocks_per_cu(int which)
 #elif DN_P <= 16
     else            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ratio_svd<DN_P, DN_NT>, DN_NT, 0);
 #else
-    else return kernel_set_generic()->blocks_per_cu(1);
+    else return kernel_set_generic()->blocks_per_cu(which);
 #endif
     return e == hipSuccess ? nb : 0;
 }

@@ -2277,7 +2277,7 @@ struct KernelSet {
     baseline_launch_fn baseline;
     init_launch_fn init;
     est_launch_fn est;
-    occupancy_fn blocks_per_cu;       // which: 0 baseline (no dynamic LDS), 1 init
+    occupancy_fn blocks_per_cu;       // which: 0 baseline (no dynamic LDS), 1 init (power iteration), 2 init (k_ratio_svd_mg, p >= 17)
     size_t static_lds_bytes;          // static LDS of k_baseline
     const char *baseline_name;
     size_t slot_extra_bytes;          // per scratch slot, behind the S-sized arrays (register-tier save area)
