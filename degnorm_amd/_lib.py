@@ -220,10 +220,12 @@ class Device:
         _check(self.lib.dn_outer_begin_scaled(self.h, _p(nm, ctypes.c_double), int(degnorm_iter)))
 
     def baseline_iteration(self, scale, nmf_iter=100, bins=20, min_high_coverage=50, downsample_rate=1,
-                           skip_baseline_selection=False, want_estimates=False, ds_start=None, want_trace=True, fetch=True):
+                           skip_baseline_selection=False, want_estimates=False, ds_start=None, want_trace=True, fetch=True,
+                           trace_out=None):
         """
         Returns (rho n x p unclipped, flags bool n, trace n x TRACE_LEN int32 or None).  fetch=False leaves the DI rows and
         flags on the device (outer_partials / outer_apply / fetch_outer work on them there) and returns (None, None, trace).
+        trace_out: an (n x TRACE_LEN) int32 array to fill instead of a fresh one (repeated runs: no new pages to fault in).
         """
         scale = np.ascontiguousarray(scale, dtype=np.float64)
         if scale.shape != (self.p,):
@@ -232,7 +234,11 @@ class Device:
                      int(bool(skip_baseline_selection)), int(bool(want_estimates)))
         rho = np.zeros((self.n, self.p)) if fetch else None
         flags = np.zeros(self.n, dtype=np.int32) if fetch else None
-        trace = np.zeros((self.n, TRACE_LEN), dtype=np.int32) if want_trace else None
+        trace = None
+        if want_trace:
+            ok = (trace_out is not None and trace_out.shape == (self.n, TRACE_LEN) and trace_out.dtype == np.int32
+                  and trace_out.flags['C_CONTIGUOUS'])
+            trace = trace_out if ok else np.empty((self.n, TRACE_LEN), dtype=np.int32)     # the library writes every entry
         dsp = None
         if ds_start is not None:
             ds_arr = np.ascontiguousarray(ds_start, dtype=np.int64)
@@ -262,13 +268,18 @@ class Device:
         avg = None if avg_di is None else np.ascontiguousarray(avg_di, dtype=np.float64)
         _check(self.lib.dn_outer_apply(self.h, None if avg is None else _p(avg, ctypes.c_double), _p(norm, ctypes.c_double), int(it)))
 
-    def fetch_outer(self):
-        """(rho, x_adj, x_weighted, ran_baseline_selection n x degnorm_iter bool) as the device holds them."""
-        rho, x_adj, xw = np.empty((self.n, self.p)), np.empty((self.n, self.p)), np.empty((self.n, self.p))
-        ran = np.zeros((self.n, self._n_iter), dtype=np.uint8)
+    def fetch_outer(self, out=None):
+        """(rho, x_adj, x_weighted, ran_baseline_selection n x degnorm_iter bool) as the device holds them.
+        out: the tuple a previous call returned, to be filled again (repeated runs: no new pages to fault in)."""
+        if out is not None and out[0].shape == (self.n, self.p) and out[3].shape == (self.n, self._n_iter):
+            rho, x_adj, xw, ran_b = out
+            ran = ran_b.view(np.uint8)
+        else:
+            rho, x_adj, xw = np.empty((self.n, self.p)), np.empty((self.n, self.p)), np.empty((self.n, self.p))
+            ran = np.empty((self.n, self._n_iter), dtype=np.uint8)
         _check(self.lib.dn_fetch_outer(self.h, _p(rho, ctypes.c_double), _p(x_adj, ctypes.c_double), _p(xw, ctypes.c_double),
                                        _p(ran, ctypes.c_uint8)))
-        return rho, x_adj, xw, ran.astype(bool)
+        return rho, x_adj, xw, ran.view(np.bool_)                       # the device writes 0 / 1
 
     def fetch_rows(self, rows):
         """Raw (unclipped) DI rows and flags of a few genes of the last baseline_iteration."""

@@ -516,7 +516,83 @@ static int size_class(dn_handle h, dn_handle_s::GeneClass &C, int32_t cols)
     return DN_OK;
 }
 
-static int finish_upload_impl(dn_handle h, const float *host_packed)
+// Where the coverage comes from: already packed host memory (one copy), or a routine that packs the genes [g0, g1) into a
+// staging buffer (dn_upload_ragged: float64 dict values -> float32, threads), called chunk by chunk while the previous
+// chunk's copy is in flight.
+struct CoverageSource {
+    const float *packed = nullptr;
+    const void *const *genes = nullptr;
+    int32_t is_f32 = 0, n_threads = 1;
+    std::atomic<int64_t> *bad = nullptr;
+};
+
+static void pack_genes(dn_handle h, const CoverageSource &src, int64_t g0, int64_t g1, float *stage)
+{
+    const int32_t p = h->p;
+    const int64_t base = h->goff[g0];
+    std::atomic<int64_t> next(g0);
+    auto work = [&]() {
+        int64_t local_bad = 0;
+        for (;;) {
+            const int64_t a = next.fetch_add(16);
+            if (a >= g1) break;
+            const int64_t b = std::min(g1, a + 16);
+            for (int64_t g = a; g < b; g++) {
+                const int64_t cnt = (int64_t) p * h->glen[g];
+                float *dst = stage + (h->goff[g] - base);
+                if (src.is_f32) std::memcpy(dst, src.genes[g], sizeof(float) * (size_t) cnt);
+                else {
+                    const double *s = (const double *) src.genes[g];
+                    for (int64_t k = 0; k < cnt; k++) { const float f = (float) s[k]; dst[k] = f; local_bad += ((double) f != s[k]); }
+                }
+            }
+        }
+        if (src.bad) *src.bad += local_bad;
+    };
+    const int nt = (int) std::max<int64_t>(1, std::min<int64_t>(src.n_threads, (g1 - g0 + 15) / 16));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+// Chunked, double-buffered upload of a ragged data set: two pinned staging buffers of ~128 MB; the host threads pack chunk
+// k + 1 while chunk k travels (a single 2 GB pinned buffer cost more to allocate than the whole copy takes).
+static int upload_ragged_chunks(dn_handle h, const CoverageSource &src)
+{
+    const int64_t n = h->n;
+    int64_t chunk = (int64_t) 32 << 20;                                     // floats per staging buffer
+    for (int64_t g = 0; g < n; g++) chunk = std::max(chunk, (int64_t) h->p * h->glen[g]);
+    chunk = std::min(chunk, std::max<int64_t>(h->total, 1));
+    float *stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = DN_OK;
+    auto cleanup = [&]() {
+        for (int b = 0; b < 2; b++) { if (stage[b]) (void) hipHostFree(stage[b]); if (done[b]) (void) hipEventDestroy(done[b]); }
+    };
+    for (int b = 0; b < 2 && rc == DN_OK; b++) {
+        if (hipHostMalloc(&stage[b], sizeof(float) * (size_t) chunk, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) rc = fail(DN_E_HIP, "upload: pinned staging buffer");
+    }
+    int64_t g0 = 0;
+    for (int k = 0; rc == DN_OK && g0 < n; k++) {
+        int64_t g1 = g0, fl = 0;
+        while (g1 < n && fl + (int64_t) h->p * h->glen[g1] <= chunk) { fl += (int64_t) h->p * h->glen[g1]; g1++; }
+        const int b = k & 1;
+        if (k >= 2 && hipEventSynchronize(done[b]) != hipSuccess) { rc = fail(DN_E_HIP, "upload: event"); break; }
+        pack_genes(h, src, g0, g1, stage[b]);
+        if (hipMemcpyAsync(h->d_cov + h->goff[g0], stage[b], sizeof(float) * (size_t) fl, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipEventRecord(done[b], h->stream) != hipSuccess) { rc = fail(DN_E_HIP, "upload: copy"); break; }
+        g0 = g1;
+    }
+    if (rc == DN_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(DN_E_HIP, "upload: synchronize");
+    if (rc != DN_OK) (void) hipStreamSynchronize(h->stream);                // nothing may still read the staging buffers
+    const std::string msg = g_err;
+    cleanup();
+    return rc == DN_OK ? DN_OK : fail(rc, msg);
+}
+
+static int finish_upload_impl(dn_handle h, const CoverageSource &src)
 {
     const int64_t n = h->n;
     const int32_t p = h->p;
@@ -558,7 +634,8 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
     HIP_TRY(hipMalloc(&h->d_tile_gene, sizeof(int32_t) * (size_t) std::max<int64_t>(h->n_tiles, 1)));
     HIP_TRY(hipMalloc(&h->d_tile_col, sizeof(int32_t) * (size_t) std::max<int64_t>(h->n_tiles, 1)));
 
-    HIP_TRY(hipMemcpyAsync(h->d_cov, host_packed, sizeof(float) * (size_t) h->total, hipMemcpyHostToDevice, h->stream));
+    if (src.packed) HIP_TRY(hipMemcpyAsync(h->d_cov, src.packed, sizeof(float) * (size_t) h->total, hipMemcpyHostToDevice, h->stream));
+    else { const int rcu = upload_ragged_chunks(h, src); if (rcu != DN_OK) return rcu; }
     HIP_TRY(hipMemcpyAsync(h->d_goff, h->goff.data(), sizeof(int64_t) * (size_t) (n + 1), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_glen, h->glen.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_order, order.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, h->stream));
@@ -660,9 +737,9 @@ static int finish_upload_impl(dn_handle h, const float *host_packed)
 }
 
 // A failed upload leaves the handle EMPTY (no resident coverage, later calls return DN_E_STATE), never half-sized.
-static int finish_upload(dn_handle h, const float *host_packed)
+static int finish_upload(dn_handle h, const CoverageSource &src)
 {
-    const int rc = finish_upload_impl(h, host_packed);
+    const int rc = finish_upload_impl(h, src);
     if (rc != DN_OK) {
         const std::string msg = g_err;
         free_device(h);
@@ -728,7 +805,9 @@ int dn_upload_packed(dn_handle h, int64_t n_genes, int32_t p, const float *packe
     if (!packed || !lengths) return fail(DN_E_INVALID, "dn_upload_packed: null argument");
     int rc = check_shape(h, n_genes, p, lengths);
     if (rc != DN_OK) return rc;
-    return finish_upload(h, packed);
+    CoverageSource src;
+    src.packed = packed;
+    return finish_upload(h, src);
 }
 
 int dn_upload_ragged(dn_handle h, int64_t n_genes, int32_t p, const void *const *genes, const int64_t *lengths,
@@ -738,35 +817,12 @@ int dn_upload_ragged(dn_handle h, int64_t n_genes, int32_t p, const void *const 
     int rc = check_shape(h, n_genes, p, lengths);
     if (rc != DN_OK) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    float *stage = nullptr;
-    HIP_TRY(hipHostMalloc(&stage, sizeof(float) * (size_t) std::max<int64_t>(h->total, 1), hipHostMallocDefault));
     if (n_threads < 1) n_threads = (int32_t) std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::atomic<int64_t> next(0), bad(0);
-    auto work = [&]() {
-        int64_t local_bad = 0;
-        for (;;) {
-            const int64_t g0 = next.fetch_add(64);
-            if (g0 >= n_genes) break;
-            const int64_t g1 = std::min(n_genes, g0 + 64);
-            for (int64_t g = g0; g < g1; g++) {
-                const int64_t cnt = (int64_t) p * h->glen[g];
-                float *dst = stage + h->goff[g];
-                if (is_f32) std::memcpy(dst, genes[g], sizeof(float) * (size_t) cnt);
-                else {
-                    const double *src = (const double *) genes[g];
-                    for (int64_t k = 0; k < cnt; k++) { const float f = (float) src[k]; dst[k] = f; local_bad += ((double) f != src[k]); }
-                }
-            }
-        }
-        bad += local_bad;
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; t++) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
+    std::atomic<int64_t> bad(0);
+    CoverageSource src;
+    src.genes = genes; src.is_f32 = is_f32; src.n_threads = n_threads; src.bad = &bad;
+    rc = finish_upload(h, src);
     if (inexact) *inexact = bad.load();
-    rc = finish_upload(h, stage);
-    (void) hipHostFree(stage);
     return rc;
 }
 

@@ -26,35 +26,9 @@
 #include <type_traits>
 #include "dn_reduce.hpp"
 
-// Spill-tier accesses: the x + lambda columns that do not fit on chip are re-read only after a whole pass, far
-// beyond an XCD's L2 share.  The non-temporal forms (DN_SPILL_NT) were measured and did not help, and neither did a
-// column-contiguous layout with 128-bit accesses (80-B lane stride: 1.25x slower than these row-wise 8-B ones).
-#ifndef DN_SPILL_NT
-#define DN_SPILL_NT 0            // bit 0: non-temporal loads, bit 1: non-temporal stores
-#endif
-#if DN_SPILL_NT & 1
-#define DN_SPILL_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define DN_SPILL_LOAD(p) (*(p))
-#endif
-#if DN_SPILL_NT & 2
-#define DN_SPILL_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#else
-#define DN_SPILL_STORE(v, p) (*(p) = (v))
-#endif
-
-#ifndef DN_GRAM_T
-#define DN_GRAM_T double
-#endif
-#ifndef DN_MIN_WAVES
-#define DN_MIN_WAVES 1
-#endif
-#ifndef DN_RAW_UNITS
-#define DN_RAW_UNITS 0           // 1: narrow cohorts keep x + lambda in raw count units (one fp64 instruction less per element and
-                                 // pass: 156 instead of 164 instructions per column at p = 10) -- parity-green, but measured 1.6 % SLOWER
-                                 // on config 2 (344.3 vs 339.0 ms per sweep), so it stays off
-#endif
-
+// Measured dead ends are recorded in DESIGN.md (section 4, "tried and not kept"), not kept here as compile-time branches:
+// non-temporal spill accesses, fp32 Gram accumulators, raw-count-units state, a lane-major tier save area, the register
+// tier as a masked loop for genes that fill it.
 namespace dn {
 
 constexpr int TRACE_LEN = 48;
@@ -155,7 +129,6 @@ struct Smem {
     double xw[W][NX];                        // per-wave totals (cross-wave combine)
     double tot[NX];                          // block totals (broadcast)
     double dsel[NX];                         // 1.0 at the packed indices of the Gram diagonal, else 0.0
-    double gsc[NX];                          // 1 / (s_i s_j) at packed index (i, j): Gram matrix of raw counts -> of scaled counts
     double stage[P >= DN_MG_MIN_P ? W * 16 * MG_STR : 2];      // per wave: 16 updated columns in the MFMA operand layout
     double eigv[P >= DN_MG_MIN_P ? W * 2 * 64 : 2];            // per wave: current eigenvector u and a work vector
     double ss[MAX_BINS];                     // per-bin mean squared residual
@@ -220,7 +193,7 @@ __device__ __forceinline__ double uniform(double v)
 // One round of the per-wave reduction: entries [OFF, OFF + CNT) of g, CNT <= 64, totals into dst[OFF + entry].
 template <int N, int OFF, typename VT>
 __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, int lane, double diag_shift, const double *dsel,
-                                                 bool shift_here, const double *gsc = nullptr)
+                                                 bool shift_here)
 {
     constexpr int CNT = (N - OFF) < 64 ? (N - OFF) : 64;
     VT part[CNT];
@@ -229,15 +202,13 @@ __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, 
     double s = wave_reduce_scatter<CNT, VT>(part, lane);
     const int e = reduce_scatter_entry(lane);
     if (e < CNT) {
-        if (gsc) s *= gsc[OFF + e];
         if (shift_here) s = fma(-diag_shift, dsel[OFF + e], s);
         dst[OFF + e] = s;
     }
-    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT>(g, dst, lane, diag_shift, dsel, shift_here, gsc);
+    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT>(g, dst, lane, diag_shift, dsel, shift_here);
 }
 
-// SCALE: the values are Gram entries of the RAW counts; the totals are multiplied by gsc (1 / (s_i s_j)) on the way out
-template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0, bool SCALE = false>    // OFF: the totals go to tot[OFF .. OFF + N)
+template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0>    // OFF: the totals go to tot[OFF .. OFF + N)
 __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm, double diag_shift = 0.0)
 {
     static_assert(OFF + N <= Smem<P, NT>::NX - 1, "xw too small");
@@ -245,14 +216,13 @@ __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm,
     constexpr int W = NT / 64;
     const int lane = lane_id(), w = wave_id();
     double *dst = ((W > 1) ? sm.xw[w] : sm.tot) + OFF;
-    wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1, (SCALE && W == 1) ? sm.gsc + OFF : nullptr);     // ceil(N / 64) rounds
+    wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1);     // ceil(N / 64) rounds
     if constexpr (W > 1) {
         __syncthreads();
         for (int e = OFF + DN_TIDX; e < OFF + N; e += NT) {         // one trip unless N > NT
             double t = sm.xw[0][e];
 #pragma unroll
             for (int ww = 1; ww < W; ww++) t += sm.xw[ww][e];
-            if constexpr (SCALE) t *= sm.gsc[e];
             if constexpr (SHIFT) t = fma(-diag_shift, sm.dsel[e], t);                // G - mu I for the eigen-solver
             sm.tot[e] = t;
         }
@@ -739,7 +709,7 @@ __device__ __forceinline__ void static_for(F &&f)
     if constexpr (I < I1) { f(std::integral_constant<int, I>{}); static_for<I + 1, I1>(f); }
 }
 
-typedef DN_GRAM_T gram_t;      // per-lane Gram accumulators: double (exact mode) or float (mixed mode)
+typedef double gram_t;         // per-lane Gram accumulators
 
 // Packed entries [LO, LO + CNT) of the Gram update only (a sweep of a Gram matrix too large for one register set).
 template <int P, int LO, int CNT, typename T>
@@ -833,7 +803,6 @@ struct GeneState {
     double rho_fb[P];    // DI of max(K_start E_start, F_start)                   nmf.py:345-346, :352-353
     double sig0;         // sigma of the first call
     double inv[P];       // 1 / scale factors
-    double scl[P];       // scale factors
     double u[P];         // outputs of the last nmf() call: top left singular vector,
     double theta;        //   sigma^2,
     double sums[2 * P + 1];   // { sum_j s_j, clamped row sums (P), row sums of Fb (P) }
@@ -884,23 +853,6 @@ __device__ __forceinline__ void col_update(const double (&f)[P], double (&a)[P],
         const double res = fma(u[i], s, -f[i]);                        // est - x                       nmf.py:94
         a[i] = fmax(fma(-c, res, a[i]), f[i]);                         // x + max(lambda - c res, 0)    nmf.py:95-97
     }
-}
-
-// The same step with the state kept in RAW count units, A = a * s_i (a = x / s + lambda is the reference's scaled state):
-//     s = u . a = sum_i (u_i / s_i) A_i = w . A,        A' = a' s_i = max(A - c s_i (u_i s) + c x, x) = max(fma(-v_i, s, fma(c, x, A)), x)
-// with w_i = u_i / s_i and v_i = c u_i s_i per solve (wave-uniform).  The raw counts enter as they are (one conversion, no
-// multiplication by 1 / s_i): 4 fp64 instructions per element instead of 5, and the cold state is x itself.  The Gram
-// matrix is accumulated in raw units too and scaled once per inner iteration on the way out of the block reduction.
-template <int P>
-__device__ __forceinline__ void col_update_raw(const double (&x)[P], double (&a)[P], const double (&w)[P], const double (&v)[P], double c)
-{
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int i = 0; i + 1 < P; i += 2) { s0 = fma(w[i], a[i], s0); s1 = fma(w[i + 1], a[i + 1], s1); }
-    if (P & 1) s0 = fma(w[P - 1], a[P - 1], s0);
-    const double s = s0 + s1;                                          // E_j * sigma = u . (x / s + lambda)_j
-#pragma unroll
-    for (int i = 0; i < P; i++) a[i] = fmax(fma(-v[i], s, fma(c, x[i], a[i])), x[i]);   // nmf.py:94-97 times s_i
 }
 
 // Wide cohorts: u and 1/s come from LDS (broadcast loads) and F = x / s is formed element by element, so that next to
@@ -992,15 +944,6 @@ __device__ __forceinline__ void load_f(gF_cptr Fb, int k, const double (&inv)[P]
     load_x<P>(Fb, k, x);
 #pragma unroll
     for (int i = 0; i < P; i++) f[i] = (double) x[i] * inv[i];
-}
-
-template <int P>
-__device__ __forceinline__ void load_xd(gF_cptr Fb, int k, double (&xd)[P])
-{
-    float x[P];
-    load_x<P>(Fb, k, x);
-#pragma unroll
-    for (int i = 0; i < P; i++) xd[i] = (double) x[i];
 }
 
 // Spill-tier layout: blocks of 64 columns, inside a block the p rows of 64 doubles back to back.  A wave (64 consecutive
@@ -1122,12 +1065,12 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
                     for (int i = 0; i < P; i++) aa[i] = (double) xr[i] * invp[i];
                 } else {
 #pragma unroll
-                    for (int i = 0; i < P; i++) aa[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
+                    for (int i = 0; i < P; i++) aa[i] = *(spill_ptr<P>(Lg, k) + i * 64);
                 }
                 if (!cold) {
                     col_update_lds<P>(xr, invp, aa, uv, c);
 #pragma unroll
-                    for (int i = 0; i < P; i++) DN_SPILL_STORE(aa[i], spill_ptr<P>(Lg, k) + i * 64);
+                    for (int i = 0; i < P; i++) *(spill_ptr<P>(Lg, k) + i * 64) = aa[i];
                 }
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
@@ -1197,18 +1140,6 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #ifndef DN_RT_MAX_P
 #define DN_RT_MAX_P 12           // above it the Gram accumulators alone need more than 256 registers
 #endif
-#ifndef DN_ONCHIP_BODY
-#define DN_ONCHIP_BODY 1         // a fourth nmf() body for genes that fill the register tier AND fit on chip (no spill tier in it)
-#endif
-#ifndef DN_GRAM_FIRST
-#define DN_GRAM_FIRST 1          // ... whose first tier column starts the Gram accumulators
-#endif
-#ifndef DN_RT_STRAIGHT
-#define DN_RT_STRAIGHT 1         // genes that fill the register tier walk it as straight-line code (no per-column exec mask)
-#endif
-#ifndef DN_RT_COLUMN_FENCE
-#define DN_RT_COLUMN_FENCE 1     // scheduling barrier between the columns of the straight-line walk
-#endif
 #ifndef DN_RT_MIN_P
 #define DN_RT_MIN_P 8            // below it a workgroup needs so few registers that several share a SIMD: left alone
 #endif
@@ -1224,7 +1155,7 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #define DN_RT_CLAIM() asm volatile("" ::: "a255")
 #else
 #define DN_REG_TIER 0
-#define DN_KERNEL_WAVES DN_MIN_WAVES
+#define DN_KERNEL_WAVES 1
 #define DN_RT_CLAIM()
 #endif
 
@@ -1311,14 +1242,7 @@ template <int P> constexpr int rt_regs_used()          // registers a0 .. a(N - 
 // Batches of RT_BATCH registers: the loads of a batch are all in flight together (one memory latency per batch, not per
 // register), and the compiler barrier between batches keeps it from gathering every register first.
 constexpr int RT_BATCH = 48;
-#ifndef DN_RT_SAVE_COALESCED
-#define DN_RT_SAVE_COALESCED 1
-#endif
-#if DN_RT_SAVE_COALESCED
 #define DN_RT_SAVE_IDX(r) ((size_t) (r) * NT + DN_TIDX)      // register-major: a wave's 64 lanes write 256 contiguous bytes
-#else
-#define DN_RT_SAVE_IDX(r) ((size_t) DN_TIDX * N + (r))       // lane-major
-#endif
 // `need`: registers a0 .. a(need - 1) are the only ones this call can write (columns beyond the gene's width are never
 // touched), so only whole batches below it are parked.
 template <int N, int NT> __device__ __forceinline__ void rt_save(int *save, int need)
@@ -1397,7 +1321,6 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     constexpr int CH = (NG + SW - 1) / SW;
     constexpr int PS = P + (P & 1);                        // LDS column stride in doubles
     const int tid = DN_TIDX;
-    constexpr bool RAW = DN_RAW_UNITS && P < DN_MG_MIN_P;  // state and Gram partials in raw count units (col_update_raw)
     constexpr int RT = DN_REG_TIER ? rt_cols<P, X16>() : 0;   // columns per lane held in AGPRs (register tier)
     constexpr int CS = rt_col_regs<P, X16>();              // registers per column: the state, and with X16 the packed raw counts
     constexpr int NR = RT * NT;                            // the gene's first NR columns
@@ -1422,12 +1345,12 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         for (int k = tid; k < n; k += NT) {
             double f[P];
 #pragma unroll
-            for (int i = 0; i < P; i++) f[i] = RAW ? (double) xq[i] : (double) xq[i] * inv[i];
+            for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
             load_x<P>(Fb, k + NT < n ? k + NT : k, xq);
             gram_add_range<P, 0, CH>(G, f);
         }
     }
-    block_sum_lds<CH, P, NT, gram_t, false, 0, RAW>(G, sm);
+    block_sum_lds<CH, P, NT, gram_t>(G, sm);
     static_for<1, SW>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int NQ = (NG - Q * CH) < CH ? (NG - Q * CH) : CH;
@@ -1437,10 +1360,10 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #pragma clang loop unroll(disable)
         for (int k = tid; k < n; k += NT) {
             double f[P];
-            if constexpr (RAW) load_xd<P>(Fb, k, f); else load_f<P>(Fb, k, inv, f);
+            load_f<P>(Fb, k, inv, f);
             gram_add_range<P, Q * CH, NQ>(Gq, f);
         }
-        block_sum_lds<NQ, P, NT, gram_t, false, Q * CH, RAW>(Gq, g_sm);
+        block_sum_lds<NQ, P, NT, gram_t, false, Q * CH>(Gq, g_sm);
     });
     {
         double tr = 0.0;
@@ -1457,12 +1380,8 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     }
     { const int r = solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, T == 0, maxs); steps += r; noconv = noconv || r > maxs; }
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
-    double uw[P], uv[P];                                              // raw units: w_i = u_i / s_i, v_i = c u_i s_i
 #pragma unroll
-    for (int i = 0; i < P; i++) {
-        u[i] = uniform(u[i]);                                         // keep u in scalar registers: two-VGPR-source FMAs
-        if constexpr (RAW) { uw[i] = uniform(u[i] * inv[i]); uv[i] = uniform(c * u[i] * g_gs.scl[i]); }
-    }
+    for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
 
     static_for<0, RT>([&](auto rc) {                             // lmbda = zeros (nmf.py:90): state a = x
         constexpr int R = decltype(rc)::value;
@@ -1472,14 +1391,14 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             double f[P];
             load_x<P>(Fb, k, xf);
 #pragma unroll
-            for (int i = 0; i < P; i++) f[i] = RAW ? (double) xf[i] : (double) xf[i] * inv[i];
+            for (int i = 0; i < P; i++) f[i] = (double) xf[i] * inv[i];
             rt_write<P, CS * R>(f);
             if constexpr (X16) rt_write_counts<P, CS * R + 2 * P>(xf);
         }
     });
     for (int k = NR + tid; k < nLe; k += NT) {
         double f[P], a[PS];
-        if constexpr (RAW) load_xd<P>(Fb, k, f); else load_f<P>(Fb, k, inv, f);
+        load_f<P>(Fb, k, inv, f);
 #pragma unroll
         for (int i = 0; i < PS; i++) a[i] = i < P ? f[i] : 0.0;
         lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
@@ -1487,7 +1406,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #ifdef DN_STAMP
     stamp[3] += __builtin_amdgcn_s_memtime() - t_cold0;
 #endif
-    constexpr bool G0 = DN_GRAM_FIRST && FULL && ONCHIP && SW == 1 && !RAW;
+    constexpr bool G0 = FULL && ONCHIP && SW == 1;          // the first tier column STARTS the Gram accumulators (no zeroing)
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
         if constexpr (!G0) {
@@ -1516,36 +1435,19 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                 auto column = [&](auto rc) {
                     constexpr int R = decltype(rc)::value;
                     double f[P], a[P];
-#if defined(DN_STAMP) && defined(DN_EXP_PHASE)      // diagnostic: cycles of ONE phase of column 0 (DN_EXP_PHASE = 1 reads, 2 update, 3 Gram, 4 writes) into stamp[2]
-#define DN_PH0(ph) long long tph_ = 0; if (R == 0 && DN_EXP_PHASE == ph) tph_ = __builtin_amdgcn_s_memtime()
-#define DN_PH1(ph) if (R == 0 && DN_EXP_PHASE == ph) stamp[2] += __builtin_amdgcn_s_memtime() - tph_
-#else
-#define DN_PH0(ph)
-#define DN_PH1(ph)
-#endif
-                    { DN_PH0(1);
                     rt_read_counts<P, CS * R + 2 * P>(f);
-                    if constexpr (!RAW) {
 #pragma unroll
-                        for (int i = 0; i < P; i++) f[i] *= inv[i];
-                    }
+                    for (int i = 0; i < P; i++) f[i] *= inv[i];
                     rt_read<P, CS * R>(a);
-                    DN_PH1(1); }
-                    { DN_PH0(2);
-                    if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
-                    DN_PH1(2); }
-                    { DN_PH0(3);
+                    col_update<P>(f, a, u, c);
                     if constexpr (G0 && R == 0) gram_set_range<P, 0, CH>(G, a); else gram_add_range<P, 0, CH>(G, a);
-                    DN_PH1(3); }
-                    { DN_PH0(4);
                     rt_write<P, CS * R>(a);
-                    DN_PH1(4); }
                 };
                 if constexpr (FULL) {
                     // every lane owns all RT columns: one straight line of code, no exec mask and no branch per column (the
                     // per-column mask costs ~90 cycles per column at one wave per SIMD: tools/ubench/clock_issue.hip); the
                     // scheduling barrier keeps the columns apart so that the register pressure stays that of one column
-                    static_for<0, RT>([&](auto rc) { column(rc); if (DN_RT_COLUMN_FENCE) __builtin_amdgcn_sched_barrier(0); });
+                    static_for<0, RT>([&](auto rc) { column(rc); __builtin_amdgcn_sched_barrier(0); });
                 } else {
                     static_for<0, RT>([&](auto rc) {
                         constexpr int R = decltype(rc)::value;
@@ -1563,10 +1465,10 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                     if (k < n) {
                         double f[P], a[P];
 #pragma unroll
-                        for (int i = 0; i < P; i++) f[i] = RAW ? (double) xq[i] : (double) xq[i] * inv[i];
+                        for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
                         if constexpr (R + 1 < RT) load_x<P>(Fb, k + NT < n ? k + NT : k, xq);
                         rt_read<P, CS * R>(a);
-                        if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
+                        col_update<P>(f, a, u, c);
                         gram_add_range<P, 0, CH>(G, a);
                         rt_write<P, CS * R>(a);
                     }
@@ -1585,12 +1487,12 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                 double f[P], a[PS];
                 lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
 #pragma unroll
-                for (int i = 0; i < P; i++) f[i] = RAW ? (double) xq[i] : (double) xq[i] * inv[i];
+                for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
                 load_x<P>(Fb, j + 1 < cnt ? k + step : k, xq);      // unconditional (clamped): no branch around the loads
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
-                if constexpr (RAW) col_update_raw<P>(f, aa, uw, uv, c); else col_update<P>(f, aa, u, c);
+                col_update<P>(f, aa, u, c);
                 gram_add_range<P, 0, CH>(G, aa);
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
@@ -1611,25 +1513,25 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                 load_x<P>(Fb, k, xn);
                 if (t > 0) {
 #pragma unroll
-                    for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
+                    for (int i = 0; i < P; i++) an[i] = *(spill_ptr<P>(Lg, k) + i * 64);
                 }
             }
 #pragma clang loop unroll(disable)
             for (int j = 0; j < cnt; j++, k += step) {
                 double f[P], a[P];
 #pragma unroll
-                for (int i = 0; i < P; i++) { f[i] = RAW ? (double) xn[i] : (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
+                for (int i = 0; i < P; i++) { f[i] = (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
                 if (j + 1 < cnt) {
                     load_x<P>(Fb, k + step, xn);
                     if (t > 0) {
 #pragma unroll
-                        for (int i = 0; i < P; i++) an[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k + step) + i * 64);
+                        for (int i = 0; i < P; i++) an[i] = *(spill_ptr<P>(Lg, k + step) + i * 64);
                     }
                 }
-                if constexpr (RAW) col_update_raw<P>(f, a, uw, uv, c); else col_update<P>(f, a, u, c);
+                col_update<P>(f, a, u, c);
                 gram_add_range<P, 0, CH>(G, a);
 #pragma unroll
-                for (int i = 0; i < P; i++) DN_SPILL_STORE(a[i], spill_ptr<P>(Lg, k) + i * 64);
+                for (int i = 0; i < P; i++) *(spill_ptr<P>(Lg, k) + i * 64) = a[i];
             }
         };
 #if defined(DN_STAMP) && defined(DN_EXP_TIER)           // diagnostic: only tier DN_EXP_TIER (1 register, 2 LDS, 3 spill) is timed into the pass slot
@@ -1644,7 +1546,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         DN_T1(0);
 #endif
         }
-        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED, 0, RAW>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
+        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
         // later sweeps (p >= 16): the remaining Gram entries from the updated state, read-only
         static_for<1, SW>([&](auto qc) {
             constexpr int Q = decltype(qc)::value;
@@ -1665,22 +1567,17 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             for (int k = kS0 + tid; k < n; k += NT) {
                 double aa[P];
 #pragma unroll
-                for (int i = 0; i < P; i++) aa[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
+                for (int i = 0; i < P; i++) aa[i] = *(spill_ptr<P>(Lg, k) + i * 64);
                 gram_add_range<P, Q * CH, NQ>(Gq, aa);
             }
-            block_sum_lds<NQ, P, NT, gram_t, Solver<P>::SHIFTED, Q * CH, RAW>(Gq, g_sm, solver.shift());
+            block_sum_lds<NQ, P, NT, gram_t, Solver<P>::SHIFTED, Q * CH>(Gq, g_sm, solver.shift());
         });
         { DN_T0();
         const int r = solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, t == T - 1, maxs);   // sigma^2 is only read after the last solve
         steps += r; noconv = noconv || r > maxs;
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-            u[i] = uniform(u[i]);
-            if constexpr (RAW) { uw[i] = uniform(u[i] * inv[i]); uv[i] = uniform(c * u[i] * g_gs.scl[i]); }
-        }
-#ifndef DN_EXP_PHASE
+        for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
         DN_T1(2);
-#endif
         }
     }
     }   // narrow cohorts
@@ -1693,10 +1590,8 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #pragma unroll
     for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
     auto fin = [&](int k, const double (&f)[P], const double (&l0)[P]) {
-        double l[P], s, r;
-#pragma unroll
-        for (int i = 0; i < P; i++) l[i] = RAW ? l0[i] * inv[i] : l0[i];          // back to the reference's scaled units
-        col_final<P>(f, l, u, first, acc, s, r);
+        double s, r;
+        col_final<P>(f, l0, u, first, acc, s, r);
         rs[k] = r;
         if (first) sv[k] = s;
     };
@@ -1729,7 +1624,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             for (int i = 0; i < P; i++) l[i] = al[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < P; i++) l[i] = DN_SPILL_LOAD(spill_ptr<P>(Lg, k) + i * 64);
+            for (int i = 0; i < P; i++) l[i] = *(spill_ptr<P>(Lg, k) + i * 64);
         }
         fin(k, f, l);
     }
@@ -1769,12 +1664,12 @@ __device__ __attribute__((noinline)) void nmf_call(const float *Fb_, double *Lg_
     if (DN_REG_TIER && __builtin_amdgcn_readfirstlane(x16_i) != 0) {
         // a third body for the genes that fill the register tier: a second variant of the tier INSIDE one body costs registers
         // the pass does not have (the allocator starts spilling Gram accumulators in the loop)
+        // and a fourth (ONCHIP) for those that also fit the register + LDS tiers: no spill tier in it
         constexpr bool X = DN_REG_TIER != 0;
-        constexpr bool ST = X && (DN_RT_STRAIGHT != 0);
         const int nL_u = __builtin_amdgcn_readfirstlane(nL);
-        if (ST && DN_ONCHIP_BODY && n_u >= rt_cols<P, X>() * NT && n_u <= rt_cols<P, X>() * NT + nL_u)
-            nmf_body<P, NT, X, ST, ST && (DN_ONCHIP_BODY != 0)>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
-        else if (ST && n_u >= rt_cols<P, X>() * NT) nmf_body<P, NT, X, ST>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+        if (X && n_u >= rt_cols<P, X>() * NT && n_u <= rt_cols<P, X>() * NT + nL_u)
+            nmf_body<P, NT, X, X, X>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
+        else if (X && n_u >= rt_cols<P, X>() * NT) nmf_body<P, NT, X, X>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
         else nmf_body<P, NT, X, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     } else nmf_body<P, NT, false>(Fb_, Lg_, rs_, sv_, n, S, nL, T, first_i);
     rt_restore<NSAVE, NT>(rtsave, need);
@@ -1814,7 +1709,7 @@ __global__ __launch_bounds__(NT * DN_UNITS, DN_KERNEL_WAVES) void k_baseline(Ite
     double *rs = sv + S;                                              // residual profile               [S]
     double *rtsave = rs + 2 * (size_t) S;                             // caller's AGPRs during an nmf() call  [RT * P][NT]
     DN_RT_CLAIM();
-    if (tid < P) { gs.inv[tid] = A.inv_scale[tid]; gs.scl[tid] = A.scale[tid]; }
+    if (tid < P) gs.inv[tid] = A.inv_scale[tid];
     if (tid == 0) gs.max_steps = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
     for (int t = tid; t < Smem<P, NT>::NX; t += NT) {                  // constants of the eigen-solver (top_eig_mfma)
         bool diag = false;
@@ -1822,12 +1717,6 @@ __global__ __launch_bounds__(NT * DN_UNITS, DN_KERNEL_WAVES) void k_baseline(Ite
         for (int i = 0; i < P; i++) diag = diag || (t == i * (i + 1) / 2 + i);
         sm.dsel[t] = diag ? 1.0 : 0.0;
         if (t == Smem<P, NT>::ZSLOT) sm.tot[t] = 0.0;
-        double sc = 1.0;
-#pragma unroll
-        for (int i = 0; i < P; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) if (t == i * (i + 1) / 2 + j) sc = A.inv_scale[i] * A.inv_scale[j];
-        sm.gsc[t] = sc;
     }
 
     for (;;) {

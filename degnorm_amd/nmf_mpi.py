@@ -185,6 +185,8 @@ class ShardedNMFOA(object):
         self.n_total = 0
         self.global_ids = None
         self.p = 0
+        self.reuse_buffers = False                        # True: repeated runs fill the same host arrays (traces, final state) again
+        self._trace_bufs, self._state_bufs = {}, None
         self.gene_names = None                            # optional: names of the local genes, for error / warning texts
         self.n_flagged = []                               # per outer iteration: genes sent through baseline selection (all ranks)
 
@@ -392,7 +394,10 @@ class ShardedNMFOA(object):
         _, _, trace = self.dev.baseline_iteration(
             self.scale_factors, nmf_iter=self.nmf_iter, bins=self.bins, min_high_coverage=self.min_high_coverage,
             downsample_rate=self.downsample_rate, skip_baseline_selection=self.skip_baseline_selection,
-            want_estimates=want_estimates, ds_start=ds, fetch=False)
+            want_estimates=want_estimates, ds_start=ds, fetch=False,
+            trace_out=self._trace_bufs.get(i) if self.reuse_buffers else None)
+        if self.reuse_buffers:
+            self._trace_bufs[i] = trace
         self._record_kernel_times()
         self.traces.append(trace)
         self._warn_unconverged(i, trace)
@@ -410,7 +415,10 @@ class ShardedNMFOA(object):
     def fetch_state(self):
         """Bring rho, x_adj, x_weighted and ran_baseline_selection back from the device (after the last iteration)."""
         if self._state_on_device:
-            self.rho, self.x_adj, self.x_weighted, ran = self.dev.fetch_outer()
+            bufs = self.dev.fetch_outer(self._state_bufs if self.reuse_buffers else None)
+            if self.reuse_buffers:
+                self._state_bufs = bufs
+            self.rho, self.x_adj, self.x_weighted, ran = bufs
             self.ran_baseline_selection = ran[:, :self.degnorm_iter]
             self._state_on_device = False
 
