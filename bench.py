@@ -272,6 +272,14 @@ def chain_parity(ref, covs, reads, nmf_iter, iters, rate, device):
     for i in range(iters):
         flipped |= np.any(m.traces[i][:, :7] != ref['history']['trace'][i][:, :7], axis=1)
     flipped |= np.any(m.ran_baseline_selection != ref['ran_baseline_selection'], axis=1)
+    detail = []
+    for k in np.flatnonzero(flipped)[:4]:                               # what differs, and from which iteration on
+        for i in range(iters):
+            td, to = m.traces[i][k, :7], ref['history']['trace'][i][k, :7]
+            if np.any(td != to) or m.ran_baseline_selection[k, i] != ref['ran_baseline_selection'][k, i]:
+                detail.append({'gene': int(k), 'first_iteration': i + 1, 'device_trace': td.tolist(), 'oracle_trace': to.tolist(),
+                               'fields': 'n_hi_cov, nmf calls, sum of active columns, exit code, loop-exit reason, drops, status'})
+                break
     ok = ~flipped
     rel = np.abs(m.rho - ref['rho']) / np.maximum(np.abs(ref['rho']), 1e-6)
     rel_adj = np.abs(m.x_adj - ref['x_adj']) / np.maximum(np.abs(ref['x_adj']), 1e-300)
@@ -282,7 +290,7 @@ def chain_parity(ref, covs, reads, nmf_iter, iters, rate, device):
            'flipped_genes': int(flipped.sum()),
            'flipped_max_abs_di': float(np.abs(m.rho - ref['rho'])[flipped].max()) if flipped.any() else 0.0,
            'flipped_max_rel_adjusted_counts': float(rel_adj[flipped].max()) if flipped.any() else 0.0,
-           'device_s': dt,
+           'flipped_detail': detail, 'device_s': dt,
            'what': 'GeneNMFOA.fit() on the cpu_baseline sample vs the oracle\'s own full run (each side follows its own scale '
                    'factors through all outer iterations, device-side outer update included); flipped = branch trace or flags differ'}
     out['ok'] = bool(out['max_rel_scale_factors'] < 1e-5 and (out['max_rel_di_final'] or 0.0) < 1e-5)
@@ -502,7 +510,8 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
                    'per_rank': [{'genes': c[0], 'wide': c[1], 'narrow': c[2], 'pair': c[3], 'total_length': c[4]} for c in counts],
                    'step': 'initial pass + {0} outer iterations + D2H of the final rho / x_adj / x_weighted / flags '
                            '(fetch_state {1:.2f} ms per step)'.format(args.iters, 1e3 * float(np.mean(fetch_s)))},
-        'rccl_ranks': ctx['rccl_ranks'], 'rccl': ctx['rccl'],
+        'rccl_ranks': ctx['rccl_ranks'],
+        'rccl': dict(ctx['rccl'] or {}, all_reduce_on_device_buffer=getattr(comm, 'device_reductions', 0) > 0) if ctx['rccl'] else None,
     }
     if config == 'c2':
         # Three gene classes = three kernels per outer iteration on three streams: class 0 (genes longer than the split

@@ -91,10 +91,7 @@ def load(build_if_missing=False):
     lib.dn_assemble_coverage.argtypes = [c.c_int, i64, i32, P(i64), P(vp), P(vp), i64, P(i64), i64, P(i32), P(i64), P(i64), P(i32),
                                          P(c.c_float), P(dbl)]
     lib.dn_assemble_last_error.restype = c.c_char_p
-    lib.dn_num_genes.argtypes = [vp]
-    lib.dn_num_genes.restype = i64
-    lib.dn_num_samples.argtypes = [vp]
-    lib.dn_num_samples.restype = i32
+    lib.dn_outer_partials_device.argtypes = [vp, P(vp)]
     _lib = lib
     return lib
 
@@ -262,6 +259,12 @@ class Device:
         out = np.zeros(3 * self.p + 4)
         _check(self.lib.dn_outer_partials(self.h, _p(out, ctypes.c_double)))
         return out
+
+    def outer_partials_device(self):
+        """The partial sums left on the device: (device address, number of doubles), for a collective on the buffer itself."""
+        ptr = ctypes.c_void_p()
+        _check(self.lib.dn_outer_partials_device(self.h, ctypes.byref(ptr)))
+        return int(ptr.value), 3 * self.p + 4
 
     def outer_apply(self, avg_di, norm, it):
         norm = np.ascontiguousarray(norm, dtype=np.float64)

@@ -1076,6 +1076,21 @@ int dn_outer_partials(dn_handle h, double *partials)
     return DN_OK;
 }
 
+int dn_outer_partials_device(dn_handle h, double **d_partials)
+{
+    if (!h || !h->d_xw) return fail(DN_E_STATE, "dn_outer_partials_device: dn_outer_begin has not been called");
+    if (!d_partials) return fail(DN_E_INVALID, "dn_outer_partials_device: null output");
+    HIP_TRY(hipSetDevice(h->device));
+    const int blocks = (int) std::min<int64_t>(OUT_BLOCKS, (h->n + 3) / 4);
+    hipLaunchKernelGGL(k_outer_partials, dim3(blocks), dim3(256), 0, h->stream, h->d_rho, h->d_rhoc, h->d_xw, h->d_trace, h->d_flags, h->d_part,
+                       (int) h->n, (int) h->p);
+    hipLaunchKernelGGL(k_outer_reduce, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_pvec, blocks, (int) h->p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));           // the collective runs on the caller's stream: the sums must be there
+    *d_partials = h->d_pvec;
+    return DN_OK;
+}
+
 int dn_outer_apply(dn_handle h, const double *avg_di, const double *norm, int32_t iter)
 {
     if (!h || !h->d_xw) return fail(DN_E_STATE, "dn_outer_apply: dn_outer_begin has not been called");
@@ -1210,8 +1225,6 @@ int dn_synchronize(dn_handle h)
     HIP_TRY(hipStreamSynchronize(h->stream));
     return DN_OK;
 }
-int64_t dn_num_genes(dn_handle h) { return h ? h->n : 0; }
-int32_t dn_num_samples(dn_handle h) { return h ? h->p : 0; }
 
 }  // extern "C"
 

@@ -76,6 +76,27 @@ class TorchComm(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
+    def allreduce_device(self, ptr, n, device_index):
+        """
+        Sum n float64 that already sit in device memory at `ptr` over all ranks, in place (RCCL reads and writes the library's
+        own buffer over xGMI), and return the totals as a numpy vector.  None if this communicator cannot (gloo, other device).
+        """
+        if (self.backend != 'nccl' or self.device.type != 'cuda' or (self.device.index or 0) != int(device_index)
+                or getattr(self, '_no_device_view', False)):
+            return None
+
+        class _Buf(object):                                           # zero-copy view of foreign device memory
+            __cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f8', 'data': (int(ptr), False), 'version': 2}
+        try:
+            t = self.torch.as_tensor(_Buf(), device=self.device)
+        except Exception as e:                                        # this torch cannot adopt the pointer: host staging from now on
+            logging.info('device-side all-reduce unavailable ({0}); staging through the host'.format(e))
+            self._no_device_view = True
+            return None
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.device_reductions = getattr(self, 'device_reductions', 0) + 1
+        return t.cpu().numpy()
+
     def Barrier(self):
         if self.backend == 'nccl':
             self.dist.barrier(group=self.group, device_ids=[self.device.index or 0])
@@ -363,14 +384,15 @@ class ShardedNMFOA(object):
             self.class_ms.append(tuple(self.dev.class_kernel_ms(c) for c in range(3)))
             self.span_ms.append(self.dev.last_span_ms())
 
-    def _reduce_and_update(self, i, partials):
+    def _reduce_and_update(self, i, partials, tot=None):
         """
         The per-sample all-reduce of an outer iteration and what every rank derives from it identically
         (nmf.py:148-158, :575-590): returns (avg_di or None, norm factors) and advances the scale factors.
         partials = [A (p), B (p), W (p), #untouched, #failed genes, #unconverged genes, #flagged genes] of this rank.
         """
         p = self.p
-        tot = _allreduce(self.comm, partials)
+        if tot is None:
+            tot = _allreduce(self.comm, partials)
         A, B, Wt, n_untouched = tot[:p], tot[p:2 * p], tot[2 * p:3 * p], tot[3 * p]
         self.n_failed.append((int(tot[3 * p + 1]), int(tot[3 * p + 2])))
         self.n_flagged.append(int(tot[3 * p + 3]))                    # ran_baseline_selection[:, i].sum() (nmf.py:571)
@@ -406,7 +428,11 @@ class ShardedNMFOA(object):
             rho_rows, flag_rows = self.dev.fetch_rows(self.history_rows)
             self.rho_raw_hist.append(rho_rows)
             self.flags_hist.append(flag_rows)
-        avg_di, norm = self._reduce_and_update(i, self.dev.outer_partials())
+        tot = None
+        if hasattr(self.comm, 'allreduce_device') and hasattr(self.dev, 'outer_partials_device'):
+            ptr, cnt = self.dev.outer_partials_device()               # the sums stay in HBM: the collective works on that buffer
+            tot = self.comm.allreduce_device(ptr, cnt, self._dev_id)
+        avg_di, norm = self._reduce_and_update(i, self.dev.outer_partials() if tot is None else None, tot)
         self.dev.outer_apply(avg_di, norm, i)
         self._state_on_device = True
         self.rho = self.x_adj = None                                  # stale until fetch_state()

@@ -130,6 +130,10 @@ int  dn_init_begin(dn_handle h, const double *reads);
 int  dn_init_partials(dn_handle h, double *partials);
 int  dn_outer_begin_scaled(dn_handle h, const double *norm, int32_t degnorm_iter);
 int  dn_outer_partials(dn_handle h, double *partials);
+/* The same sums left ON THE DEVICE for a device-side collective (RCCL all-reduce over xGMI on the buffer itself, no host
+ * hop; nmf_mpi.py:796-838 moves the whole DI matrix through rank 0 instead): *d_partials receives the device address of the
+ * 3p + 4 doubles, valid until the next dn_outer_* call on this handle; the library's stream has been synchronised.          */
+int  dn_outer_partials_device(dn_handle h, double **d_partials);
 int  dn_outer_apply(dn_handle h, const double *avg_di, const double *norm, int32_t iter);
 int  dn_fetch_outer(dn_handle h, double *rho, double *x_adj, double *x_weighted, uint8_t *ran);
 int  dn_fetch_rows(dn_handle h, int64_t n_rows, const int64_t *rows, double *rho_raw, int32_t *flags);
@@ -178,9 +182,6 @@ const char *dn_class_kernel_name(dn_handle h, int cls);
 int  dn_synchronize(dn_handle h);
 /* Stream-copy ceiling of this device (GB/s, float4 copy of `bytes` bytes, best of `reps`).          */
 double dn_measure_copy_gbps(dn_handle h, int64_t bytes, int reps);
-/* Raw device pointer / count accessors for torch interop (partial sums for the RCCL all-reduce).    */
-int64_t dn_num_genes(dn_handle h);
-int32_t dn_num_samples(dn_handle h);
 
 #ifdef __cplusplus
 }
