@@ -562,6 +562,7 @@ static int upload_ragged_chunks(dn_handle h, const CoverageSource &src)
 {
     const int64_t n = h->n;
     int64_t chunk = (int64_t) 32 << 20;                                     // floats per staging buffer
+    if (const char *env = getenv("DN_UPLOAD_CHUNK_FLOATS")) chunk = std::max<int64_t>(1, atoll(env));    // tests: many small chunks
     for (int64_t g = 0; g < n; g++) chunk = std::max(chunk, (int64_t) h->p * h->glen[g]);
     chunk = std::min(chunk, std::max<int64_t>(h->total, 1));
     float *stage[2] = {nullptr, nullptr};

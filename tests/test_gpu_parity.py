@@ -755,3 +755,44 @@ def test_downsample_hint_only_changes_the_kernel_family(device, oracle):
     prm = oracle.make_params(nmf_iter=25, min_high_coverage=2, downsample_rate=rate)
     rho_o = oracle.baseline_batch(covs, scale, prm, ds_start=offs)[0]
     np.testing.assert_allclose(out[1][0], rho_o, rtol=1e-8, atol=1e-10)
+
+
+def test_chunked_upload_and_reused_buffers(monkeypatch):
+    """
+    dn_upload_ragged packs and copies in chunks through two pinned staging buffers (here forced to ~25 chunks): same device
+    contents as the packed upload; the wrapper's timings cover the call; a second run of an engine with reuse_buffers fills the
+    SAME host arrays with the same numbers.
+    """
+    from collections import OrderedDict
+    from degnorm_amd import _lib
+    from degnorm_amd.nmf import GeneNMFOA
+    from degnorm_amd.nmf_mpi import ShardedNMFOA
+    c = synth.CONFIGS['c2']
+    covs = _genes(c['seed'], range(48), c['p'], c['l_min'], c['l_max'])
+    reads = np.vstack([synth.read_counts_from_coverage(x) for x in covs])
+    monkeypatch.setenv('DN_UPLOAD_CHUNK_FLOATS', str(60000))              # a gene is up to 50 000 floats: about two genes per chunk
+    a = _lib.Device(0)
+    a.upload(covs, n_threads=3)
+    ea, ca, _ = a.ratio_svd_sums()
+    monkeypatch.delenv('DN_UPLOAD_CHUNK_FLOATS')
+    b = _lib.Device(0)
+    b.upload_packed(np.concatenate([x.astype(np.float32).ravel() for x in covs]), [x.shape[1] for x in covs], c['p'])
+    eb, cb, _ = b.ratio_svd_sums()
+    np.testing.assert_array_equal(ca, cb)
+    np.testing.assert_array_equal(ea, eb)
+    a.close(); b.close()
+
+    m = GeneNMFOA(degnorm_iter=2, nmf_iter=20)
+    m.fit(OrderedDict(('g%d' % k, x) for k, x in enumerate(covs)), reads)
+    assert set(m.timings) == {'pack_upload_s', 'run_s', 'estimates_s', 'fetch_state_s'} and all(v >= 0 for v in m.timings.values())
+
+    eng = ShardedNMFOA(device=0, degnorm_iter=2, nmf_iter=20)
+    eng.reuse_buffers = True
+    eng.load(covs, reads)
+    eng.run(want_estimates=False)
+    rho1, tr1 = eng.rho, eng.traces[0]
+    keep = rho1.copy()
+    eng.run(want_estimates=False)
+    assert eng.rho is rho1 and eng.traces[0] is tr1                       # the same arrays, filled again
+    np.testing.assert_array_equal(eng.rho, keep)
+    np.testing.assert_allclose(m.rho, keep, rtol=1e-12)

@@ -81,7 +81,8 @@ def _nccl_worker(port, out_q):
         eng.run(want_estimates=False)
         comm.Barrier()
         out_q.put(dict(rho=eng.rho, x_adj=eng.x_adj, flags=eng.ran_baseline_selection, probe=probe,
-                       rccl='.'.join(str(v) for v in torch.cuda.nccl.version())))
+                       rccl='.'.join(str(v) for v in torch.cuda.nccl.version()),
+                       device_reductions=getattr(comm, 'device_reductions', 0), n_flagged=list(eng.n_flagged)))
     finally:
         dist.destroy_process_group()
 
@@ -107,6 +108,10 @@ def test_sharded_driver_over_rccl_world_size_1():
     np.testing.assert_allclose(res['x_adj'], G['single_x_adj'], rtol=1e-9)
     np.testing.assert_array_equal(res['flags'], G['single_flags'])
     assert res['rccl']
+    # the per-iteration collective ran IN PLACE on the library's device buffer (dn_outer_partials_device), once per iteration,
+    # and carried the count of genes sent through baseline selection
+    assert res['device_reductions'] == int(G['degnorm_iter'])
+    np.testing.assert_array_equal(res['n_flagged'], G['single_flags'].sum(axis=0))
 
 
 def test_outer_update_on_the_device_equals_the_host_update():
