@@ -29,6 +29,14 @@
 // Measured dead ends are recorded in DESIGN.md (section 4, "tried and not kept"), not kept here as compile-time branches:
 // non-temporal spill accesses, fp32 Gram accumulators, raw-count-units state, a lane-major tier save area, the register
 // tier as a masked loop for genes that fill it.
+// Diagnostic ISA builds (-DDN_MARKS, tools/isa_regions.py): named comment lines in the generated assembly, so that the
+// instructions of each phase of an inner iteration can be counted statically.  Never defined for the product.
+#ifdef DN_MARKS
+#define DN_MARK(name) asm volatile("; DN_MARK " name)
+#else
+#define DN_MARK(name)
+#endif
+
 namespace dn {
 
 constexpr int TRACE_LEN = 48;
@@ -217,6 +225,7 @@ __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm,
     const int lane = lane_id(), w = wave_id();
     double *dst = ((W > 1) ? sm.xw[w] : sm.tot) + OFF;
     wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1);     // ceil(N / 64) rounds
+    DN_MARK("wave_reduced");
     if constexpr (W > 1) {
         __syncthreads();
         for (int e = OFF + DN_TIDX; e < OFF + N; e += NT) {         // one trip unless N > NT
@@ -429,6 +438,7 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
         h[kb] = g[kb];
         v[kb] = st.v[kb];
     }
+    DN_MARK("solver_loaded");
 #pragma unroll
     for (int m = 0; m < M; m++) {
         const dn_double4 d = mfma_sym<KB>(h, h);
@@ -466,6 +476,7 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
         v[kb] = u2;
     }
     double d2_prev = allsum_rows(e1p), d2 = allsum_rows(e2p);
+    DN_MARK("solver_checked");
     double n_last = n2 * i2, i_prev = i1;                               // |y2| and 1 / |y1|: y2 = H y1
     int steps = 1 + (2 << M);
     // as in top_eig_rows: stop when the error predicted from the contraction between two checks is ~1e-13
@@ -1409,10 +1420,12 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     constexpr bool G0 = FULL && ONCHIP && SW == 1;          // the first tier column STARTS the Gram accumulators (no zeroing)
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
+        DN_MARK("iter_begin");
         if constexpr (!G0) {
 #pragma unroll
             for (int i = 0; i < CH; i++) G[i] = 0.0;
         }
+        DN_MARK("zeroed");
         { DN_T0();
         // The columns are walked forwards on even passes and backwards on odd ones (spill tier first, then the LDS tier):
         // what the previous pass touched last -- the end of the spill state and of the counts -- is still in the XCD's
@@ -1539,14 +1552,16 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #else
 #define DN_TIER(id, call) call
 #endif
-        if constexpr (G0) { DN_TIER(1, reg_tier()); DN_TIER(2, lds_tier()); }       // the register tier touches no memory: its place is free
-        else if (dir > 0) { DN_TIER(1, reg_tier()); DN_TIER(2, lds_tier()); DN_TIER(3, spill_tier()); }
-        else { DN_TIER(3, spill_tier()); DN_TIER(2, lds_tier()); DN_TIER(1, reg_tier()); }
+        if constexpr (G0) { DN_MARK("reg_tier"); DN_TIER(1, reg_tier()); DN_MARK("lds_tier"); DN_TIER(2, lds_tier()); }       // the register tier touches no memory: its place is free
+        else if (dir > 0) { DN_MARK("reg_tier"); DN_TIER(1, reg_tier()); DN_MARK("lds_tier"); DN_TIER(2, lds_tier()); DN_MARK("spill_tier"); DN_TIER(3, spill_tier()); }
+        else { DN_MARK("spill_tier_b"); DN_TIER(3, spill_tier()); DN_MARK("lds_tier_b"); DN_TIER(2, lds_tier()); DN_MARK("reg_tier_b"); DN_TIER(1, reg_tier()); }
+        DN_MARK("pass_end");
 #if !(defined(DN_STAMP) && defined(DN_EXP_TIER))
         DN_T1(0);
 #endif
         }
         { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
+        DN_MARK("reduced");
         // later sweeps (p >= 16): the remaining Gram entries from the updated state, read-only
         static_for<1, SW>([&](auto qc) {
             constexpr int Q = decltype(qc)::value;
@@ -1577,6 +1592,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         steps += r; noconv = noconv || r > maxs;
 #pragma unroll
         for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
+        DN_MARK("solved");
         DN_T1(2);
         }
     }
