@@ -28,7 +28,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from .utils import split_into_chunks, partition_by_length
+from .utils import split_into_chunks, partition_by_cost
 from .results import write_results
 
 __all__ = ['run_gene_nmfoa_mpi', 'save_results', 'ShardedNMFOA', 'TorchComm', 'LocalComm']
@@ -487,8 +487,8 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
     ``cov_dat`` (OrderedDict gene -> p x L) and ``reads_dat`` (n x p) and ships each worker its share once
     (nmf_mpi.py:603-629) -- as ONE packed float32 buffer per worker (the layout the device consumes: half the bytes of
     the reference's float64 pickles and no per-gene objects); every rank then keeps its genes on its own GPU.
-    ``partition`` (extra): 'balanced' deals the genes by length so that every GPU gets the same total length
-    (utils.partition_by_length), 'contiguous' is the reference's equal-count chunking (nmf_mpi.py:605); per-gene
+    ``partition`` (extra): 'balanced' deals the genes by predicted cost so that every GPU gets the same share of every gene
+    class (utils.partition_by_cost), 'contiguous' is the reference's equal-count chunking (nmf_mpi.py:605); per-gene
     results do not depend on it (the down-sampling offsets are drawn per global gene id), rows come back in the
     original order.  Input errors found on rank 0 are raised on EVERY rank (nobody is left waiting in a receive), and
     a rank without genes (fewer chunks than ranks, nmf_mpi.py:613) takes part in the collectives with zeros.
@@ -519,7 +519,7 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
             if partition == 'contiguous':
                 parts = split_into_chunks(list(range(n_genes)), size)    # nmf_mpi.py:605
             elif partition == 'balanced':
-                parts = partition_by_length(li_vec, size)
+                parts = partition_by_cost(li_vec, size, p=p, downsample_rate=abs(int(downsample_rate)))
             else:
                 raise ValueError("partition must be 'balanced' or 'contiguous'")
             while len(parts) < size:                                      # fewer chunks than ranks: idle ranks get nothing

@@ -141,6 +141,26 @@ def test_partition_by_length_is_balanced_and_complete():
     assert [len(q) for q in partition_by_length([5, 9], 4)] == [1, 1, 0, 0]
 
 
+def test_partition_by_cost_balances_cost_and_classes():
+    """The sharded run's default partition: complete, ordered, the same predicted cost and the same share of every gene class
+    (each class is its own kernel and queue on a GPU) on every rank; down-sampled regime; fewer genes than ranks."""
+    from degnorm_amd.utils import partition_by_cost, predicted_gene_cost
+    rng = np.random.default_rng(4)
+    lengths = rng.integers(200, 5001, size=20000)
+    parts = partition_by_cost(lengths, 8)
+    assert sorted(g for q in parts for g in q) == list(range(20000))
+    assert all(q == sorted(q) for q in parts)
+    cost = predicted_gene_cost(lengths)
+    tot = np.array([cost[q].sum() for q in parts])
+    assert tot.max() / tot.mean() < 1.001
+    for lo, hi in ((3819, 10 ** 9), (1875, 3819), (0, 1875)):                   # wide / narrow / pair class at p = 10
+        cnt = [int(((lengths[q] > lo) & (lengths[q] <= hi)).sum()) for q in parts]
+        assert max(cnt) - min(cnt) <= 2
+    parts = partition_by_cost(rng.integers(501, 5001, size=999), 4, p=50, downsample_rate=500)
+    assert sorted(g for q in parts for g in q) == list(range(999)) and max(map(len, parts)) - min(map(len, parts)) <= 25
+    assert sorted(len(q) for q in partition_by_cost([5, 9], 4)) == [0, 0, 1, 1]
+
+
 def test_single_rank_sharded_equals_single_node(oracle_device):
     """LocalComm (size 1) through the sharded driver == the reference's single-node result."""
     from degnorm_amd.nmf_mpi import ShardedNMFOA
