@@ -34,7 +34,6 @@ Rank 0 prints ONE JSON line with the driver contract fields plus
   also          (default run only) config 4 measured in the same process after config 2.
 """
 import argparse
-import glob
 import hashlib
 import json
 import os
@@ -116,9 +115,13 @@ def launch_ranks(n, argv, launcher=None):
 # accounting helpers
 # ---------------------------------------------------------------------------------------------------------------------
 def source_hash():
-    """sha256 over the kernel sources and the build recipe: identifies the binary build() makes from this tree."""
+    """sha256 over the sources of the config-2 class kernels (the templates, the reduction, the instantiation unit) and the build
+    recipe with its flags: identifies the kernel code the PMC passes were taken on.  The host side (dn_api.hip) and the
+    run-time-p family are not part of it; what the host side decides -- which genes run in which class kernel -- is checked
+    separately (kernel names and gene counts of the profile against the run)."""
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, 'degnorm_amd', 'csrc', '*.h*'))) + [os.path.join(ROOT, 'degnorm_amd', 'build.py')]
+    files = [os.path.join(ROOT, 'degnorm_amd', 'csrc', f) for f in ('dn_inst.hip', 'dn_kernels.hpp', 'dn_reduce.hpp')] + \
+            [os.path.join(ROOT, 'degnorm_amd', 'build.py')]
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, 'rb').read())
@@ -435,6 +438,8 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
 
     eng = ShardedNMFOA(comm=comm, device=local_rank, degnorm_iter=args.iters, nmf_iter=args.nmf_iter, downsample_rate=rate)
     eng.reuse_buffers = True        # every step fills the same host arrays (per-gene counters, final state): a step is a repeated run
+    eng.trace_columns = 8           # per iteration the 8 counters of a gene come back (n_hi_cov, calls, columns, exit, ..., solver steps), not
+                                    # the dropped-bin sequence behind them (diagnostics: 9.6 MB per iteration on config 4)
     t_up = time.time()
     eng.load_packed(packed, lengths, p, reads, global_ids=np.asarray(my_genes, dtype=np.int64), n_total=n_genes)
     t_up = time.time() - t_up

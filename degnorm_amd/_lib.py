@@ -55,6 +55,7 @@ def load(build_if_missing=False):
     lib.dn_upload_packed.argtypes = [vp, i64, i32, P(c.c_float), P(i64)]
     lib.dn_set_downsample_hint.argtypes = [vp, i32]
     lib.dn_set_solver_step_cap.argtypes = [vp, i32]
+    lib.dn_set_trace_columns.argtypes = [vp, i32]
     lib.dn_ratio_svd_sums.argtypes = [vp, P(dbl), P(dbl), P(i32)]
     lib.dn_baseline_iteration.argtypes = [vp, P(dbl), P(Params), P(i64), P(dbl), P(i32), P(i32)]
     lib.dn_fetch_estimates.argtypes = [vp, P(dbl)]
@@ -124,6 +125,7 @@ class Device:
         self.p = 0
         self.lengths = None
         self.inexact = 0
+        self.trace_cols = TRACE_LEN
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h.value:
@@ -140,6 +142,12 @@ class Device:
     def hint_downsample(self, rate):
         """Announce the take-every rate before an upload (kernel-family choice only; see dn_set_downsample_hint)."""
         _check(self.lib.dn_set_downsample_hint(self.h, int(max(1, rate))))
+        return self
+
+    def set_trace_columns(self, cols):
+        """Leading trace columns copied back per iteration (8 .. TRACE_LEN; default all).  baseline_iteration then returns n x cols."""
+        _check(self.lib.dn_set_trace_columns(self.h, int(cols)))
+        self.trace_cols = int(cols)
         return self
 
     def set_solver_step_cap(self, max_steps):
@@ -233,9 +241,9 @@ class Device:
         flags = np.zeros(self.n, dtype=np.int32) if fetch else None
         trace = None
         if want_trace:
-            ok = (trace_out is not None and trace_out.shape == (self.n, TRACE_LEN) and trace_out.dtype == np.int32
+            ok = (trace_out is not None and trace_out.shape == (self.n, self.trace_cols) and trace_out.dtype == np.int32
                   and trace_out.flags['C_CONTIGUOUS'])
-            trace = trace_out if ok else np.empty((self.n, TRACE_LEN), dtype=np.int32)     # the library writes every entry
+            trace = trace_out if ok else np.empty((self.n, self.trace_cols), dtype=np.int32)     # the library writes every entry
         dsp = None
         if ds_start is not None:
             ds_arr = np.ascontiguousarray(ds_start, dtype=np.int64)

@@ -270,6 +270,16 @@ __global__ __launch_bounds__(256) void k_gather_rows(const double *__restrict__ 
     if (i == 0) out_flags[k] = flags[rows[k]];
 }
 
+// the first `cols` counters of every gene, packed: what comes back to the host per iteration when the caller does not want the
+// whole trace (dn_set_trace_columns)
+__global__ __launch_bounds__(256) void k_trace_head(const int32_t *__restrict__ trace, int32_t *__restrict__ head, long long n_cols_total, int cols)
+{
+    for (long long t = (long long) blockIdx.x * 256 + threadIdx.x; t < n_cols_total; t += (long long) gridDim.x * 256) {
+        const long long g = t / cols;
+        head[t] = trace[g * dn::TRACE_LEN + (t - g * cols)];
+    }
+}
+
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -364,8 +374,10 @@ struct dn_handle_s {
     int32_t ds_hint = 1;          // take-every rate the caller intends to use (dn_set_downsample_hint); 1 = none
     int32_t max_steps = dn::EIG_MAX_STEPS_DEFAULT;   // step cap of one eigen-solve (dn_set_solver_step_cap)
     // per-gene counters of the previous dn_baseline_iteration: the narrow class orders its queue by the work they predict
-    int32_t *host_trace = nullptr;        // pinned (hipHostMalloc): the per-gene counters come back every iteration (n x TRACE_LEN)
+    int32_t *host_trace = nullptr;        // pinned (hipHostMalloc): the per-gene counters come back every iteration (n x trace_cols)
     size_t host_trace_len = 0;
+    int32_t trace_cols = dn::TRACE_LEN;   // leading trace columns copied back per iteration (dn_set_trace_columns)
+    int32_t *d_trace_head = nullptr;      // n x trace_cols, packed (only when trace_cols < TRACE_LEN)
     bool have_trace = false;
 
 };
@@ -378,6 +390,7 @@ static void free_device(dn_handle h)
                     h->d_part, h->d_pvec, h->d_ran, h->d_x};
     for (void *q : ptrs) if (q && q != (void *) h->cls[0].d_ws) (void) hipFree(q);
     if (h->host_trace) { (void) hipHostFree(h->host_trace); h->host_trace = nullptr; h->host_trace_len = 0; }
+    if (h->d_trace_head) { (void) hipFree(h->d_trace_head); h->d_trace_head = nullptr; }
     for (auto &c : h->cls) {
         if (c.d_order) (void) hipFree(c.d_order);
         if (c.d_counter) (void) hipFree(c.d_counter);
@@ -793,6 +806,15 @@ int dn_set_downsample_hint(dn_handle h, int32_t rate)
     return DN_OK;
 }
 
+int dn_set_trace_columns(dn_handle h, int32_t cols)
+{
+    if (!h) return fail(DN_E_INVALID, "null handle");
+    if (cols < 8 || cols > dn::TRACE_LEN) return fail(DN_E_INVALID, "trace columns must be in [8, DN_TRACE_LEN]");
+    h->trace_cols = cols;
+    h->have_trace = false;                                // the host copy changes shape: no stale counters for the queue order
+    return DN_OK;
+}
+
 int dn_set_solver_step_cap(dn_handle h, int32_t max_steps)
 {
     if (!h) return fail(DN_E_INVALID, "null handle");
@@ -929,7 +951,7 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
             std::vector<std::pair<double, int32_t>> key((size_t) C.n);
             for (int32_t k = 0; k < C.n; k++) {
                 const int32_t g = C.order[k];
-                const int32_t *tr = &h->host_trace[(size_t) g * dn::TRACE_LEN];
+                const int32_t *tr = &h->host_trace[(size_t) g * h->trace_cols];
                 key[k] = {(double) tr[2] + per_call * (double) tr[1] + 1e-3 * (double) h->glen[g], g};
             }
             std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; });
@@ -962,15 +984,25 @@ int dn_baseline_iteration(dn_handle h, const double *scale, const dn_params *prm
         HIP_TRY(hipMemcpyAsync(rho, h->d_rho, sizeof(double) * (size_t) h->n * h->p, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t) h->n, hipMemcpyDeviceToHost, h->stream));
     }
-    if (h->host_trace_len < (size_t) h->n * dn::TRACE_LEN) {
+    const int32_t tcols = h->trace_cols;
+    const size_t trace_ints = (size_t) h->n * (size_t) tcols;
+    if (h->host_trace_len < trace_ints) {
         if (h->host_trace) { (void) hipHostFree(h->host_trace); h->host_trace = nullptr; h->host_trace_len = 0; }
-        HIP_TRY(hipHostMalloc((void **) &h->host_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipHostMallocDefault));
-        h->host_trace_len = (size_t) h->n * dn::TRACE_LEN;
+        HIP_TRY(hipHostMalloc((void **) &h->host_trace, sizeof(int32_t) * trace_ints, hipHostMallocDefault));
+        h->host_trace_len = trace_ints;
     }
-    HIP_TRY(hipMemcpyAsync(h->host_trace, h->d_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN, hipMemcpyDeviceToHost, h->stream));
+    if (tcols == dn::TRACE_LEN)
+        HIP_TRY(hipMemcpyAsync(h->host_trace, h->d_trace, sizeof(int32_t) * trace_ints, hipMemcpyDeviceToHost, h->stream));
+    else {
+        if (!h->d_trace_head) HIP_TRY(hipMalloc(&h->d_trace_head, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN));
+        hipLaunchKernelGGL(k_trace_head, dim3((unsigned) std::min<size_t>(1024, (trace_ints + 255) / 256)), dim3(256), 0, h->stream,
+                           h->d_trace, h->d_trace_head, (long long) trace_ints, (int) tcols);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->host_trace, h->d_trace_head, sizeof(int32_t) * trace_ints, hipMemcpyDeviceToHost, h->stream));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_trace = (prm->downsample_rate <= 1);          // with down-sampling the active columns are redrawn every iteration
-    if (trace) std::memcpy(trace, h->host_trace, sizeof(int32_t) * (size_t) h->n * dn::TRACE_LEN);
+    if (trace) std::memcpy(trace, h->host_trace, sizeof(int32_t) * trace_ints);
     h->last_span_ms = 0.f;
     for (int c = 0; c < dn_handle_s::NCLS; c++) {
         if (h->cls[c].n == 0) continue;

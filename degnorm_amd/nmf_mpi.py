@@ -206,6 +206,7 @@ class ShardedNMFOA(object):
         self.n_total = 0
         self.global_ids = None
         self.p = 0
+        self.trace_columns = None                         # leading trace columns fetched per iteration (None: all; >= 8: the counters)
         self.reuse_buffers = False                        # True: repeated runs fill the same host arrays (traces, final state) again
         self._trace_bufs, self._state_bufs = {}, None
         self.gene_names = None                            # optional: names of the local genes, for error / warning texts
@@ -223,6 +224,8 @@ class ShardedNMFOA(object):
         partition-invariant down-sampling offsets); n_total: genes over all ranks; n_threads: host packing threads
         (0: as many as the box has, at most 16)."""
         if len(cov_mats) > 0:
+            if self.trace_columns is not None and hasattr(self.dev, 'set_trace_columns'):
+                self.dev.set_trace_columns(self.trace_columns)
             self.dev.hint_downsample(self.downsample_rate)
             self.dev.upload(cov_mats, n_threads=n_threads)
             if getattr(self.dev, 'inexact', 0):
@@ -233,6 +236,8 @@ class ShardedNMFOA(object):
 
     def load_packed(self, packed, lengths, p, reads, global_ids=None, n_total=None):
         if len(lengths) > 0:
+            if self.trace_columns is not None and hasattr(self.dev, 'set_trace_columns'):
+                self.dev.set_trace_columns(self.trace_columns)
             self.dev.hint_downsample(self.downsample_rate)
             self.dev.upload_packed(packed, lengths, p)
         self._set_reads(reads, len(lengths), p, global_ids, n_total)

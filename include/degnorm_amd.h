@@ -80,6 +80,10 @@ int  dn_set_downsample_hint(dn_handle h, int32_t rate);
 /* Step cap of one on-chip eigen-solve in power-step equivalents (default 4000; the reference's ARPACK call has
  * maxiter = 10 n, scipy eigsh via svds, nmf.py:63).  A gene whose solve hits the cap gets status -4.                    */
 int  dn_set_solver_step_cap(dn_handle h, int32_t max_steps);
+/* Leading columns of the per-gene trace that dn_baseline_iteration copies back (8 .. DN_TRACE_LEN, default all): the
+ * counters [0..8) are what a production run reads; the dropped-bin sequence [8..40) is diagnostics (at 50 000 genes the whole
+ * trace is 9.6 MB per iteration).  `trace` of dn_baseline_iteration then holds n x cols int32.                            */
+int  dn_set_trace_columns(dn_handle h, int32_t cols);
 int  dn_upload_ragged(dn_handle h, int64_t n_genes, int32_t p, const void *const *genes,
                       const int64_t *lengths, int32_t is_f32, int32_t n_threads, int64_t *inexact);
 int  dn_upload_packed(dn_handle h, int64_t n_genes, int32_t p, const float *packed,

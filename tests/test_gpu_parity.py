@@ -799,3 +799,27 @@ def test_chunked_upload_and_reused_buffers(monkeypatch):
     assert eng.rho is rho1 and eng.traces[0] is tr1                       # the same arrays, filled again
     np.testing.assert_array_equal(eng.rho, keep)
     np.testing.assert_allclose(m.rho, keep, rtol=1e-12)
+
+
+def test_trace_columns_are_a_prefix_of_the_full_trace(device):
+    """dn_set_trace_columns: the compact per-iteration copy (counters only) equals the leading columns of the whole trace;
+    the narrow-class queue re-ordering, which reads those counters, gives the same results either way."""
+    from degnorm_amd import _lib
+    c = synth.CONFIGS['c2']
+    covs = _genes(c['seed'], range(64), c['p'], c['l_min'], c['l_max'])
+    out = []
+    for cols in (_lib.TRACE_LEN, 8, 12):
+        dev = _lib.Device(0)
+        dev.set_trace_columns(cols)
+        dev.upload(covs)
+        res = [dev.baseline_iteration(np.linspace(0.9, 1.1, c['p']), nmf_iter=15) for _ in range(2)]     # second call: re-ordered queue
+        assert res[1][2].shape == (len(covs), cols)
+        out.append(res[1])
+        dev.close()
+    for rho, flags, trace in out[1:]:
+        np.testing.assert_array_equal(trace, out[0][2][:, :trace.shape[1]])
+        np.testing.assert_array_equal(rho, out[0][0])
+        np.testing.assert_array_equal(flags, out[0][1])
+    with pytest.raises(ValueError):
+        device.set_trace_columns(4)
+    device.set_trace_columns(_lib.TRACE_LEN)
