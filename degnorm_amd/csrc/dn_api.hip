@@ -677,7 +677,10 @@ static int finish_upload_impl(dn_handle h, const CoverageSource &src)
             const int64_t lds_n = (160 * 1024) / per_cu_n - (int64_t) narrow->static_lds_bytes - 256;
             const int64_t lds_cols_n = std::max<int64_t>(0, lds_n / (8 * (int64_t) (p + (p & 1))));
             const int64_t reg_cols_n = narrow->reg_tier_cols;
-            h->split_len = (int32_t) (reg_cols_n > 0 ? (int64_t) (1.7 * (double) (reg_cols_n + lds_cols_n)) : (int64_t) (2.1 * (double) lds_cols_n));
+            // round 3: 1.775 x capacity (4 000 bases at p = 10) instead of 1.7 x (3 831): the same on the full configuration (-0.2 %), but
+            // +2.4 % at the shard sizes of 2 and 8 GPUs (10 000 / 2 500 genes: 727 vs 745 ms, 191 vs 196 ms per run) -- with few genes
+            // per GPU the wide class (one gene per CU, launched first) is what quantises: 500 instead of 595 genes on 256 slots
+            h->split_len = (int32_t) (reg_cols_n > 0 ? (int64_t) (1.775 * (double) (reg_cols_n + lds_cols_n)) : (int64_t) (2.1 * (double) lds_cols_n));
         }
         if (!narrow) h->split_len = 0;
         if (!env && p >= 25) h->split_len = 0;     // wide cohorts (MFMA Gram): one class measured 3-5 % faster than two
