@@ -38,8 +38,8 @@ def predicted_gene_cost(lengths, p=10, downsample_rate=1):
     L = np.asarray(lengths, dtype=np.float64)
     if downsample_rate > 1:
         return np.ceil(L / float(downsample_rate)) + 64.0
-    lanes = np.where(L > 3819, 256.0, np.where(L > 1875, 128.0, 64.0))       # wide / narrow / pair class (p = 10 boundaries)
-    per_col = np.where(L > 3819, 1.25, 1.0)                                  # the wide class spills: ~25 % more per column
+    lanes = np.where(L > 4000, 256.0, np.where(L > 1888, 128.0, 64.0))       # wide / narrow / pair class (p = 10 boundaries)
+    per_col = np.where(L > 4000, 1.25, 1.0)                                  # the wide class spills: ~25 % more per column
     # columns per lane x cost per column + fixed part worth ~6 columns per lane, times the SIMDs the gene occupies
     return (L / lanes * per_col + 6.0) * (lanes / 64.0)
 
@@ -55,7 +55,7 @@ def partition_by_cost(lengths, n, p=10, downsample_rate=1):
     n = int(n)
     L = np.asarray(lengths, dtype=np.int64)
     cost = predicted_gene_cost(L, p, downsample_rate)
-    cls = np.where(L > 3819, 0, np.where(L > 1875, 1, 2))
+    cls = np.where(L > 4000, 0, np.where(L > 1888, 1, 2))
     order = np.lexsort((np.arange(len(L)), -cost))                           # most expensive first, stable
     parts = [[] for _ in range(n)]
     load = np.zeros(n)

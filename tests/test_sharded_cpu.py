@@ -153,7 +153,7 @@ def test_partition_by_cost_balances_cost_and_classes():
     cost = predicted_gene_cost(lengths)
     tot = np.array([cost[q].sum() for q in parts])
     assert tot.max() / tot.mean() < 1.001
-    for lo, hi in ((3819, 10 ** 9), (1875, 3819), (0, 1875)):                   # wide / narrow / pair class at p = 10
+    for lo, hi in ((4000, 10 ** 9), (1888, 4000), (0, 1888)):                   # wide / narrow / pair class at p = 10
         cnt = [int(((lengths[q] > lo) & (lengths[q] <= hi)).sum()) for q in parts]
         assert max(cnt) - min(cnt) <= 2
     parts = partition_by_cost(rng.integers(501, 5001, size=999), 4, p=50, downsample_rate=500)
