@@ -706,6 +706,8 @@ def run_rank(args):
         out['also'] = {'config 4': {k: sub[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline',
                                                         'parity', 'cpu_baseline', 'setup')}}
     if pg is not None:
+        if world > 1:
+            comm.Barrier()                                              # rank 0's post-clock checks are over: everybody leaves together
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
