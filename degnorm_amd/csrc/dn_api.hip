@@ -861,6 +861,8 @@ int dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *
     a.cov = h->d_cov; a.goff = h->d_goff; a.glen = h->d_glen; a.order = h->d_order; a.counter = h->d_counter;
     a.est_sums = h->d_est_sums; a.cov_sums = h->d_cov_sums; a.status = h->d_status; a.n_genes = (int32_t) h->n;
     a.p = h->p; a.ws = h->d_ws; a.slot_bytes = h->slot_bytes; a.S = h->S; a.max_steps = h->max_steps;
+    a.x16 = h->d_x16;
+    { const char *f64 = getenv("DN_INIT_FP64"); a.force_fp64 = (f64 && f64[0] == '1') ? 1 : 0; }
     HIP_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * 4, h->stream));
     // occupancy of the kernel that ks->init() will start: from 17 samples on it is the matrix-core variant (round 2 asked for
     // the power-iteration kernel's figure here and ran k_ratio_svd_mg at ONE workgroup per CU instead of two)

@@ -762,6 +762,140 @@ __device__ __forceinline__ void mg_gram_pass(const float *x, int L, int p)
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Pass 1, integer-exact, on the i8 matrix cores (round 3).  Coverage is whole-number counts; when every count of the gene fits
+// 16 bits (k_row_max's x16 flag) a count is x = 256 h + l with two bytes, stored offset by 128 as SIGNED bytes h', l', and
+//     sum_c x_i x_j = 65536 HH_ij + 256 (HL_ij + HL_ji) + LL_ij + K (r_i + r_j) + n K^2,     K = 32 896, r_i = 256 sum_c h'_i + sum_c l'_i
+// with three byte Gram matrices accumulated EXACTLY in int32 by v_mfma_i32_16x16x64_i8 (16 cycles for 64 columns of a 16 x 16
+// tile; the fp64 form takes 64 cycles for 4 columns: 160 MFMA-cycles per column of a 64-row matrix against 10 here).  p <= 63.  As in the
+// fp64 pass which columns share an instruction does not matter, so lane (i = l & 15, kb = l >> 4) loads the 16 consecutive
+// counts c0 + 16 kb .. + 15 of row 16 t + i (64 contiguous bytes; a row's 256 bytes per wave) and the same registers serve as
+// A and as B operand.  Row p is a row of ones in l' (zeros in h'): r_j falls out of the same products.  Every wave takes
+// 64-column groups round-robin; a wave's int32 tiles hold at most 2 x 16 384 x (L / 4) -- genes longer than 2^17 bases take
+// the fp64 pass.  The tiles are combined in fp64 (sums of integers below 2^53: exact) into g_mg like the fp64 pass's.
+// ---------------------------------------------------------------------------------------------------
+typedef int dn_int4 __attribute__((ext_vector_type(4)));
+
+template <int TR>
+__device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L, int p)
+{
+    constexpr int NTILE = TR * (TR + 1) / 2;
+    constexpr int W = NT / 64;
+    const int lane = lane_id(), w = wave_id();
+    const int li = lane & 15, lk = lane >> 4;
+    dn_int4 hh[NTILE], ll[NTILE], hl[NTILE];
+#pragma unroll
+    for (int i = 0; i < NTILE; i++) { hh[i] = dn_int4{0, 0, 0, 0}; ll[i] = hh[i]; hl[i] = hh[i]; }
+    gF_cptr rowp[TR];
+    unsigned keep[TR], ones[TR];
+#pragma unroll
+    for (int t = 0; t < TR; t++) {
+        const int row = 16 * t + li;
+        rowp[t] = (gF_cptr) x + (size_t) (row < p ? row : 0) * L + 16 * lk;
+        keep[t] = row < p ? 0xffffffffu : 0u;                               // padding rows: zero bytes (after the offset)
+        ones[t] = row == p ? 0x01010101u : 0u;                              // the row of ones (in l')
+    }
+    // bytes of four counts -> one dword of low bytes, one of high bytes (both offset by 128: x ^ 0x80 per byte)
+    auto pack4 = [](const dn_f4 &v, unsigned &lo, unsigned &hi) {
+        const unsigned u0 = (unsigned) v.x, u1 = (unsigned) v.y, u2 = (unsigned) v.z, u3 = (unsigned) v.w;
+        const unsigned t01 = __builtin_amdgcn_perm(u1, u0, 0x05010400u);   // u0.b0 u1.b0 u0.b1 u1.b1
+        const unsigned t23 = __builtin_amdgcn_perm(u3, u2, 0x05010400u);
+        lo = __builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u;
+        hi = __builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u;
+    };
+    auto products = [&](const dn_int4 (&H)[TR], const dn_int4 (&Lo)[TR]) {
+        int tix = 0;
+#pragma unroll
+        for (int t1 = 0; t1 < TR; t1++)
+#pragma unroll
+            for (int t2 = 0; t2 <= t1; t2++, tix++) {
+                hh[tix] = __builtin_amdgcn_mfma_i32_16x16x64_i8(H[t1], H[t2], hh[tix], 0, 0, 0);
+                ll[tix] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Lo[t1], Lo[t2], ll[tix], 0, 0, 0);
+                hl[tix] = __builtin_amdgcn_mfma_i32_16x16x64_i8(H[t1], Lo[t2], hl[tix], 0, 0, 0);      // HL + LH: both into one tile
+                hl[tix] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Lo[t1], H[t2], hl[tix], 0, 0, 0);
+            }
+    };
+    const int nfull = L / 64;
+#pragma clang loop unroll(disable)
+    for (int g = w; g < nfull; g += W) {
+        dn_int4 H[TR], Lo[TR];
+#pragma unroll
+        for (int t = 0; t < TR; t++) {
+            dn_f4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = *(gF4_cptr) (rowp[t] + 64 * g + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                unsigned lo, hi;
+                pack4(v[q], lo, hi);
+                Lo[t][q] = (int) ((lo & keep[t]) | ones[t]);
+                H[t][q] = (int) (hi & keep[t]);
+            }
+        }
+        products(H, Lo);
+    }
+    if ((L & 63) && w == nfull % W) {                                        // the partial last group: columns beyond L are zero bytes
+        dn_int4 H[TR], Lo[TR];
+        const int c = 64 * nfull + 16 * lk;
+#pragma unroll
+        for (int t = 0; t < TR; t++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                dn_f4 v;
+                unsigned m = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int col = c + 4 * q + e;
+                    v[e] = col < L ? rowp[t][64 * nfull + 4 * q + e] : 0.0f;
+                    m |= col < L ? (0xffu << (8 * e)) : 0u;
+                }
+                unsigned lo, hi;
+                pack4(v, lo, hi);
+                Lo[t][q] = (int) (((lo & keep[t]) | ones[t]) & m);
+                H[t][q] = (int) (hi & keep[t] & m);
+            }
+        }
+        products(H, Lo);
+    }
+    // tile (t1, t2): register r of lane (c = l & 15, q = l >> 4) holds entry [16 t1 + 4 q + r][16 t2 + c]
+    for (int ww = 0; ww < W; ww++) {
+        if (w == ww) {
+            int tix = 0;
+#pragma unroll
+            for (int t1 = 0; t1 < TR; t1++)
+#pragma unroll
+                for (int t2 = 0; t2 <= t1; t2++, tix++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * t1 + 4 * lk + r, col = 16 * t2 + li;
+                        const double v = fma(65536.0, (double) hh[tix][r], fma(256.0, (double) hl[tix][r], (double) ll[tix][r]));
+                        if (ww == 0) g_mg[row * MG_LD + col] = v;
+                        else g_mg[row * MG_LD + col] += v;
+                    }
+        }
+        __syncthreads();
+    }
+    // offsets: r_i = 256 sum h'_i + sum l'_i sits in row p (the row of ones); x = 256 h' + l' + K
+    constexpr int R = 16 * TR;
+    constexpr double K = 32896.0;
+    const double nK2 = (double) L * K * K;
+    for (int idx = threadIdx.x; idx < R * R; idx += NT) {
+        const int r = idx / R, c = idx - r * R;
+        if (c <= r && r < p) {
+            const double ri = g_mg[p * MG_LD + r], rj = g_mg[p * MG_LD + c];
+            g_mg[r * MG_LD + c] += fma(K, ri + rj, nK2);                      // integers below 2^53: exact
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < p) g_mg[p * MG_LD + threadIdx.x] += (double) L * K;    // row p: the plain row sums (cov_sums)
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < R * R; idx += NT) {                    // mirror: the solver walks whole rows
+        const int r = idx / R, c = idx - r * R;
+        if (c > r) g_mg[r * MG_LD + c] = g_mg[c * MG_LD + r];
+    }
+    __syncthreads();
+}
+
 // Top eigenvector of the p x p block of g_mg (p <= 64) by ONE wave: lane r keeps to row r of the matrix in LDS (row stride
 // MG_LD = 81 doubles: the 64 lanes hit different banks), the vectors live in g_mv and are read with broadcast loads, norms and
 // the Rayleigh quotient are all-reduced over the lanes in registers -- no barrier inside the iteration (the block-wide form
@@ -924,7 +1058,12 @@ __global__ __launch_bounds__(NT, 2) void k_ratio_svd_mg(InitArgs A)
 #endif
         if (L < 2) status = ST_VALUE_ERROR;
         else {
-            if (TR <= 2) mg_gram_pass<2>(x, L, p);
+            const bool bytes_ok = TR <= 4 && A.x16 && A.x16[g] != 0 && L <= (1 << 17) && !A.force_fp64;     // else: the fp64 matrix cores
+            if (bytes_ok) {
+                if (TR <= 2) mg_gram_pass_i8<2>(x, L, p);
+                else if (TR == 3) mg_gram_pass_i8<3>(x, L, p);
+                else mg_gram_pass_i8<4>(x, L, p);
+            } else if (TR <= 2) mg_gram_pass<2>(x, L, p);
             else if (TR == 3) mg_gram_pass<3>(x, L, p);
             else if (TR == 4) mg_gram_pass<4>(x, L, p);
             else mg_gram_pass<5>(x, L, p);

@@ -100,6 +100,8 @@ struct InitArgs {
     char          *ws;         // scratch slots (generic kernels only)
     int64_t        slot_bytes;
     int32_t        S;
+    const int32_t *x16;        // n: every count of the gene is a whole number <= 65535 (k_row_max): the integer-exact Gram pass may run
+    int32_t        force_fp64; // diagnostics (DN_INIT_FP64=1): keep the fp64 Gram pass also where the integer-exact one applies
 };
 
 struct EstArgs {

@@ -823,3 +823,41 @@ def test_trace_columns_are_a_prefix_of_the_full_trace(device):
     with pytest.raises(ValueError):
         device.set_trace_columns(4)
     device.set_trace_columns(_lib.TRACE_LEN)
+
+
+@pytest.mark.parametrize('p', [17, 33, 50, 63])
+def test_integer_exact_gram_pass_vs_fp64_pass_and_oracle(oracle, monkeypatch, p):
+    """
+    The initial pass of wide cohorts forms the Gram matrix of whole-number counts EXACTLY on the i8 matrix cores (two bytes
+    per count, int32 accumulation; mg_gram_pass_i8) where every count fits 16 bits, and on the fp64 matrix cores otherwise:
+    both against the oracle, and against each other, on genes with partial last column groups, fewer than 64 columns, a zero
+    sample, counts at the 16-bit limit, and one gene that does NOT fit (falls back to fp64 by itself).
+    """
+    from degnorm_amd import _lib
+    rng = np.random.default_rng(500 + p)
+    covs = [synth.synth_gene(77, g, p, 300, 3000)[0] for g in range(20)]
+    covs.append(rng.poisson(30, size=(p, 37)).astype(float))                       # shorter than one 64-column group
+    covs.append(rng.poisson(30, size=(p, 64)).astype(float))                       # exactly one group
+    covs.append(np.vstack([np.zeros((1, 700)), rng.poisson(9, size=(p - 1, 700))]).astype(float))     # a zero sample
+    big = rng.integers(60000, 65536, size=(p, 333)).astype(float)                  # at the 16-bit limit: offsets, no int32 overflow
+    big[0, 0] = 65535.0
+    covs.append(big)
+    over = rng.poisson(50, size=(p, 500)).astype(float)
+    over[3, 17] = 70000.0                                                          # does not fit 16 bits: the fp64 pass serves this gene
+    covs.append(over)
+    out = {}
+    for mode in ('i8', 'fp64'):
+        if mode == 'fp64':
+            monkeypatch.setenv('DN_INIT_FP64', '1')
+        dev = _lib.Device(0)
+        dev.upload(covs)
+        out[mode] = dev.ratio_svd_sums()
+        dev.close()
+    monkeypatch.delenv('DN_INIT_FP64')
+    est_o, cov_o, status_o = oracle.ratio_svd_batch(covs)
+    for mode in out:
+        est, cov, status = out[mode]
+        assert not status.any() and not status_o.any()
+        np.testing.assert_array_equal(cov, cov_o)                                  # sums of whole numbers: exact on every path
+        np.testing.assert_allclose(est, est_o, rtol=1e-10, atol=1e-7)
+    np.testing.assert_allclose(out['i8'][0], out['fp64'][0], rtol=1e-11, atol=1e-7)
