@@ -749,7 +749,7 @@ def test_downsample_hint_only_changes_the_kernel_family(device, oracle):
         dev.hint_downsample(hint)
         dev.upload(covs)
         rho, flags, trace = dev.baseline_iteration(scale, nmf_iter=25, min_high_coverage=2, downsample_rate=rate, ds_start=offs)
-        out.append((rho, flags, trace, dev.class_kernel_name(0)))
+        out.append((rho, flags, trace, dev.main_kernel_name()))       # (the wide class may be empty: no gene beyond the class boundary)
         dev.close()
     assert out[0][3].startswith('k_baseline<10') and out[1][3] == 'gen_rows::k_baseline_gen'
     np.testing.assert_array_equal(out[0][1], out[1][1])
