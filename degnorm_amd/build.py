@@ -25,7 +25,7 @@ NT_LIST = (WIDE_NT, 128)
 # pair build (one wavefront per gene, two genes per 128-thread workgroup): where the register tier exists (dn_kernels.hpp
 # DN_RT_MIN_P .. DN_RT_MAX_P; dn_inst.hip refuses to compile a pair unit without it).  The list is handed to dn_api.hip as the
 # DN_P_PAIR X-macro, so the dispatcher there cannot drift from what is compiled here.
-PAIR_P_LIST = [q for q in P_LIST if int(os.environ.get('DN_RT_MIN_P', 8)) <= q <= int(os.environ.get('DN_RT_MAX_P', 12))]
+PAIR_P_LIST = [q for q in P_LIST if int(os.environ.get('DN_RT_MIN_P', 2)) <= q <= int(os.environ.get('DN_RT_MAX_P', 12))]
 EXTRA = ['-D' + d for d in os.environ.get('DN_DEFINES', '').split() if d]   # e.g. DN_DEFINES='DN_STAMP=1'
 for _k in ('DN_RT_MIN_P', 'DN_RT_MAX_P'):             # the same bounds reach the kernels that PAIR_P_LIST was derived from
     if _k in os.environ:

@@ -51,7 +51,7 @@ DN_FOR_EACH_P(DN_DECL)
 // Pair build (dn_inst.hip -DDN_PAIR): 128-thread workgroups carrying two genes, one per wavefront, for the shortest genes;
 // compiled where the register tier exists
 #ifndef DN_P_PAIR                 // build.py passes the list it compiles (-D'DN_P_PAIR(X)=X(8) ...'): ONE source of truth
-#define DN_P_PAIR(X) X(8) X(9) X(10) X(11) X(12)
+#define DN_P_PAIR(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 #endif
 #define DN_DECL(P) const KernelSet *kernel_set_p##P##_pair();
 DN_P_PAIR(DN_DECL)

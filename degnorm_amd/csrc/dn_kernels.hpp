@@ -1154,8 +1154,9 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #define DN_RT_MAX_P 12           // above it the Gram accumulators alone need more than 256 registers
 #endif
 #ifndef DN_RT_MIN_P
-#define DN_RT_MIN_P 8            // below it a workgroup needs so few registers that several share a SIMD: left alone
-#endif
+#define DN_RT_MIN_P 2            // round 3: the tier (and with it the pair class) serves every p <= 12.  Round 2 stopped at 8 ("below it a
+#endif                           // workgroup needs so few registers that several share a SIMD") -- measured on config-2-shaped genes: p = 3
+                                 // +31 %, 4 +7 %, 5 +31 %, 6 +26 %, 7 +47 % genes/s (tools/p_sweep.py, profiles/round3/p_sweep.txt)
 #if defined(DN_P) && DN_P >= DN_RT_MIN_P && DN_P <= DN_RT_MAX_P && !defined(DN_NO_REG_TIER)
 #define DN_REG_TIER 1
 #define DN_KERNEL_WAVES 2        // the register ALLOCATOR's budget: 512 / 2 registers (the kernel really runs one wave per SIMD)
