@@ -119,6 +119,8 @@ __device__ __attribute__((noinline)) void nmf_gen(const float *Fb, double *A, do
     if (tid < p) g_st.u[tid] = 1.0 / sqrt((double) p);
     __syncthreads();
     int st = top_singular(A, sj, n, S, p);                                // SVD of x (nmf.py:88)
+    bool cold_every_solve = false;                                        // dn_kernels.hpp, warm_start_unsafe
+    for (int i = 0; i < p; i++) cold_every_solve = cold_every_solve || g_st.u[i] < WARM_START_MIN_COMPONENT;
     const double c = 1.0 / sqrt((double) T);
     for (int t = 0; t < T && st == ST_OK; t++) {
         for (int k = tid; k < n; k += NT) {
@@ -131,6 +133,10 @@ __device__ __attribute__((noinline)) void nmf_gen(const float *Fb, double *A, do
             }
         }
         __syncthreads();
+        if (cold_every_solve) {
+            if (tid < p) g_st.u[tid] = 1.0 / sqrt((double) p);
+            __syncthreads();
+        }
         st = top_singular(A, sj, n, S, p);
     }
     if (st != ST_OK) { if (tid == 0) g_st.status = st; __syncthreads(); return; }
@@ -225,6 +231,7 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
         double theta = 0.0;
         int steps = 0, st = ST_OK;
         bool noconv = false;
+        bool cold_every_solve = false;                                  // dn_kernels.hpp, warm_start_unsafe (here: columns in blocks)
 #pragma clang loop unroll(disable)
         for (int t = -1; t < T; t++) {                                  // t = -1: SVD of x itself (nmf.py:88)
             if (t >= 0) {
@@ -252,9 +259,23 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             wave_fence();
             if (lane < NSM) tot[lane * (lane + 1) / 2 + lane] -= est.mu;   // the solver takes G - mu I
             wave_fence();
-            const int r = top_eig_mfma<NSM>(tot, ROWS_ZSLOT, v, theta, est, t == T - 1, g_st.max_steps);
+            int r;
+            if (!cold_every_solve) r = top_eig_mfma<NSM>(tot, ROWS_ZSLOT, v, theta, est, t == T - 1, g_st.max_steps);
+            else {                                                      // columns in blocks without a common sample: block by block
+                Solver<NSM> sol;
+                sol.st = est;
+                r = solve_by_blocks<NSM>(sol, tot, ROWS_ZSLOT, v, theta, g_st.max_steps, n);
+                est = sol.st;
+            }
             steps += r;
             if (r > g_st.max_steps) noconv = true;
+            if (t < 0) {
+                double vm = v[0];
+#pragma unroll
+                for (int j = 1; j < NSM; j++) vm = (j < n && v[j] < vm) ? v[j] : vm;
+                cold_every_solve = __builtin_amdgcn_readfirstlane((int) (vm < WARM_START_MIN_COMPONENT)) != 0;
+                if (cold_every_solve) est.mu = 0.0;                      // block-by-block solves run unshifted (Solver::no_shift)
+            }
             wave_fence();
         }
         if (st == ST_OK) {
@@ -470,7 +491,7 @@ __global__ __launch_bounds__(NT, DN_GEN_MINW) void k_baseline_gen(IterArgs A)
                         first = false;
                     } else {
                         bool zero_row = false;
-                        for (int i = 0; i < p; i++) zero_row = zero_row || (g_st.u[i] * g_st.S == 0.0);
+                        for (int i = 0; i < p; i++) zero_row = zero_row || (g_st.rsum[i] == 0.0);   // see dn_kernels.hpp, nmf.py:315
                         __syncthreads();
                         if (tid == 0) {
                             const double sg = sqrt(g_st.theta);

@@ -861,3 +861,39 @@ def test_integer_exact_gram_pass_vs_fp64_pass_and_oracle(oracle, monkeypatch, p)
         np.testing.assert_array_equal(cov, cov_o)                                  # sums of whole numbers: exact on every path
         np.testing.assert_allclose(est, est_o, rtol=1e-10, atol=1e-7)
     np.testing.assert_allclose(out['i8'][0], out['fp64'][0], rtol=1e-11, atol=1e-7)
+
+
+def test_sparse_genes_vs_reference_golden(oracle):
+    """
+    tests/golden/sparse.npz (generated with the reference): samples in blocks without a common base -- the top singular vector
+    jumps between the blocks as lambda grows, which a warm-started power iteration cannot follow (the safe path: csrc/dn_kernels.hpp
+    solve_by_blocks) --, samples that lose all coverage when a bin is dropped (nmf.py:315), fewer active columns than bins or samples.
+    Every sample count of the fixture goes through the templated kernels; the down-sampled genes also through the one-wavefront
+    family (hint_downsample).  Device against the reference's outputs, and against the oracle for the branch trace.
+    """
+    from test_oracle_golden import sparse_golden_cases
+    from degnorm_amd import _lib
+    n = n_dec = 0
+    for c in sparse_golden_cases():
+        for hint in ((False, True) if c['rate'] > 1 else (False,)):
+            dev = _lib.Device(0)
+            try:
+                if hint:
+                    dev.hint_downsample(c['rate'])
+                dev.upload([c['x']])
+                kw = dict(nmf_iter=c['T'], bins=c['bins'], min_high_coverage=c['mhc'], want_estimates=True)
+                if c['rate'] > 1:
+                    kw.update(downsample_rate=c['rate'], ds_start=np.array([c['off']], dtype=np.int64))
+                rho, flags, trace = dev.baseline_iteration(c['scale'], **kw)
+                est = dev.fetch_estimates()
+                name = dev.main_kernel_name()
+            finally:
+                dev.close()
+            msg = 'sparse golden gene %d (%s, p=%d, rate %d, kernel %s)' % (c['k'], c['kind'], c['x'].shape[0], c['rate'], name)
+            assert trace[0, 6] == 0, msg
+            assert trace[0, 1] == len(c['calls']) and trace[0, 2] == c['calls'].sum(), msg
+            assert bool(flags[0]) == c['flag'], msg
+            np.testing.assert_allclose(rho[0], c['rho'], rtol=1e-8, atol=1e-10, err_msg=msg)
+            np.testing.assert_allclose(est[0].sum(axis=1), c['est_rowsum'], rtol=1e-8, atol=1e-8, err_msg=msg)
+        n += 1; n_dec += c['decoupled']
+    assert n >= 60 and n_dec >= 20

@@ -201,33 +201,35 @@ def test_register_tier_registers_are_private(tier_isa, p, nt):
             tier_regs.setdefault(fn, set()).update(regs)
         else:
             compiler_agpr[fn] = compiler_agpr.get(fn, 0) + 1
-    call = [f for f in tier_regs if 'nmf_call' in f]
-    assert len(call) == 1 and all('nmf_call' in f for f in tier_regs)          # the tier is touched in nmf_call only
+    call = sorted(f for f in tier_regs if 'nmf_call' in f)
+    # the tier is touched in nmf_call only: the function of the four hot bodies and its twin for the safe repeat (SAFE = true)
+    assert len(call) == 2 and all('nmf_call' in f for f in tier_regs)
     def cols(regs_per_col):
         return min(12, 256 // regs_per_col) * regs_per_col
     n_tier = max(cols(2 * p), cols(2 * p + (p + 1) // 2))                       # without / with the packed counts
-    assert tier_regs[call[0]] == set(range(n_tier))                             # a0 .. a(n_tier - 1), all of them
-    assert compiler_agpr.get(call[0], 0) == 0                                   # (1)
     text = open(out).read()
-    body = text[text.index(call[0] + ':'):]
-    body = body[:body.index('.Lfunc_end')]
-    blocks = [b for b in re.findall(r';;#ASMSTART(.*?);;#ASMEND', body, flags=re.S) if 'v_accvgpr' in b]
     regs_of = lambda bs: set(int(x) for b in bs for x in re.findall(r'\ba(\d+)\b', b))
-    assert all('v_accvgpr_read_b32' in b for b in blocks[:n_tier]) and regs_of(blocks[:n_tier]) == set(range(n_tier))     # (2) the save comes first
-    # ... and every return of the function (the epilogue is duplicated for the early exits) sits behind a full restore
-    runs, cur = [], []
-    for b in blocks:
-        if 'v_accvgpr_write_b32' in b:
-            cur.append(b)
-        else:
-            if cur:
-                runs.append(cur)
-            cur = []
-    if cur:
-        runs.append(cur)
-    restores = [r for r in runs if len(r) >= n_tier and regs_of(r[-n_tier:]) == set(range(n_tier))]
-    assert len(restores) >= len(re.findall(r's_setpc_b64 s\[30:31\]', body)) >= 1     # returns (other s_setpc are long branches)
-    assert all('v_accvgpr_write_b32' in b for b in blocks[-n_tier:]) and regs_of(blocks[-n_tier:]) == set(range(n_tier))
+    for fn_call in call:
+        assert tier_regs[fn_call] == set(range(n_tier))                         # a0 .. a(n_tier - 1), all of them
+        assert compiler_agpr.get(fn_call, 0) == 0                               # (1)
+        body = text[text.index(fn_call + ':'):]
+        body = body[:body.index('.Lfunc_end')]
+        blocks = [b for b in re.findall(r';;#ASMSTART(.*?);;#ASMEND', body, flags=re.S) if 'v_accvgpr' in b]
+        assert all('v_accvgpr_read_b32' in b for b in blocks[:n_tier]) and regs_of(blocks[:n_tier]) == set(range(n_tier))     # (2) the save comes first
+        # ... and every return of the function (the epilogue is duplicated for the early exits) sits behind a full restore
+        runs, cur = [], []
+        for b in blocks:
+            if 'v_accvgpr_write_b32' in b:
+                cur.append(b)
+            else:
+                if cur:
+                    runs.append(cur)
+                cur = []
+        if cur:
+            runs.append(cur)
+        restores = [r for r in runs if len(r) >= n_tier and regs_of(r[-n_tier:]) == set(range(n_tier))]
+        assert len(restores) >= len(re.findall(r's_setpc_b64 s\[30:31\]', body)) >= 1     # returns (other s_setpc are long branches)
+        assert all('v_accvgpr_write_b32' in b for b in blocks[-n_tier:]) and regs_of(blocks[-n_tier:]) == set(range(n_tier))
     if pair:
         # the two wavefronts of a pair workgroup walk different genes: a workgroup barrier anywhere in the kernel would deadlock
         kb = text[text.index('_ZN2dn8nmf_call'):text.index('.amdhsa_kernel _ZN2dn10k_baseline')]

@@ -1,0 +1,158 @@
+"""
+Randomised differential run of the device path against the CPU oracle (test infrastructure, like tests/): seeded batches of
+genes with random sample counts, lengths, depth regimes and pathological structure (empty samples, empty stretches,
+piecewise-constant coverage = exact ties, counts beyond 16 bits, non-integer coverage, strong 3' decay), random scale
+factors, nmf_iter, bins, min_high_coverage and down-sampling.  Every batch is compared like the parity tests: branch trace
+and flags exact, DI and estimates to 1e-8.  Mismatching genes are listed with their traces (a tie flip shows as a trace
+that differs by one column / one drop; anything else is a bug to chase).
+usage (GPU box): python tools/fuzz_parity.py [--rounds 40] [--seed 1] [--out gpurun_out/fuzz/fuzz.txt]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def make_gene(rng, p, L, kind):
+    env = 1.0 + np.abs(np.sin(np.linspace(0, rng.uniform(0.5, 7), L) + rng.uniform(0, 3)))
+    depth = float(rng.choice([0.3, 3.0, 30.0, 300.0, 3000.0]))
+    mean = depth * np.outer(rng.lognormal(0, 0.5, p), env)
+    if kind == 'plain':
+        return rng.poisson(mean).astype(float)
+    if kind == 'decay':                                    # 3' bias in some samples: the drop-bin loop runs long
+        for i in range(p):
+            if rng.random() < 0.5:
+                mean[i] *= np.linspace(rng.uniform(0.02, 0.8), 1.0, L) ** rng.uniform(0.5, 3)
+        return rng.poisson(mean).astype(float)
+    if kind == 'empty_sample':
+        x = rng.poisson(mean).astype(float)
+        x[rng.integers(0, p)] = 0.0
+        return x
+    if kind == 'holes':                                    # stretches without coverage in every sample
+        x = rng.poisson(mean).astype(float)
+        for _ in range(int(rng.integers(1, 4))):
+            a = int(rng.integers(0, L)); b = min(L, a + int(rng.integers(1, max(2, L // 3))))
+            x[:, a:b] = 0.0
+        return x
+    if kind == 'steps':                                    # piecewise constant, small integers: exact ties everywhere
+        k = int(rng.integers(1, 9))
+        edges = np.sort(rng.integers(0, L, size=k))
+        lvl = rng.integers(0, 6, size=(p, k + 1)).astype(float)
+        x = np.zeros((p, L))
+        prev = 0
+        for j, e in enumerate(list(edges) + [L]):
+            x[:, prev:e] = lvl[:, j:j + 1]
+            prev = e
+        return x
+    if kind == 'big':                                      # counts beyond 16 bits: the variant without packed counts
+        x = rng.poisson(mean).astype(float)
+        x[rng.integers(0, p), rng.integers(0, L, size=max(1, L // 50))] = float(rng.integers(65536, 400000))
+        return x
+    if kind == 'fractional':                               # not whole numbers (still exact in fp32)
+        return rng.poisson(mean).astype(float) + rng.choice([0.0, 0.25, 0.5], size=(p, L))
+    if kind == 'rank1':
+        return np.outer(rng.integers(1, 9, size=p), rng.integers(0, 50, size=L)).astype(float)
+    if kind == 'spike':                                    # one very deep base
+        x = rng.poisson(mean).astype(float)
+        x[:, rng.integers(0, L)] *= 40.0
+        return x
+    raise ValueError(kind)
+
+
+KINDS = ['plain', 'plain', 'decay', 'decay', 'empty_sample', 'holes', 'steps', 'big', 'fractional', 'rank1', 'spike']
+
+
+def one_round(rng, device_cls, oracle, log, budget_cols):
+    p = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 11, 12, 13, 14, 15, 16, 17, 19, 24, 32, 33, 47, 50, 64]))
+    rate = int(rng.choice([1, 1, 1, 1, 40, 200, 500]))
+    n_genes = int(rng.integers(1, 90))
+    covs, kinds = [], []
+    for g in range(n_genes):
+        if rate > 1:
+            L = int(rng.integers(rate + 1, min(13 * rate, 6000) + 1)) if rng.random() < 0.8 else int(rng.integers(rate + 1, 6001))   # the reference refuses rate >= a gene's length
+        else:
+            r = rng.random()
+            L = int(rng.integers(1, 130)) if r < 0.15 else int(rng.integers(130, 2500)) if r < 0.8 else int(rng.integers(2500, budget_cols))
+        kind = str(rng.choice(KINDS))
+        covs.append(make_gene(rng, p, L, kind))
+        kinds.append(kind)
+    scale = np.exp(rng.uniform(-1.2, 1.2, p)) if rng.random() < 0.5 else np.linspace(0.9, 1.15, p)
+    T = int(rng.choice([1, 2, 5, 9, 20, 40]))
+    bins = int(rng.choice([2, 5, 20, 20, 20, 33]))
+    mhc = int(rng.choice([2, 10, 50, 50])) if rate == 1 else 2
+    skip = bool(rng.random() < 0.1)
+    offs = rng.integers(0, rate, size=n_genes).astype(np.int64) if rate > 1 else None
+    what = 'p={0} genes={1} rate={2} T={3} bins={4} mhc={5} skip={6} L=[{7},{8}]'.format(
+        p, n_genes, rate, T, bins, mhc, skip, min(c.shape[1] for c in covs), max(c.shape[1] for c in covs))
+    dev = device_cls(0)
+    try:
+        if rate > 1 and rng.random() < 0.7:
+            dev.hint_downsample(rate)
+        dev.upload(covs)
+        kw = dict(nmf_iter=T, bins=bins, min_high_coverage=mhc, skip_baseline_selection=skip, want_estimates=True)
+        if rate > 1:
+            kw.update(downsample_rate=rate, ds_start=offs)
+        rho, flags, trace = dev.baseline_iteration(scale, **kw)
+        est = dev.fetch_estimates()
+        names = [dev.class_kernel_name(k) for k in range(3)]
+    finally:
+        dev.close()
+    prm = oracle.make_params(nmf_iter=T, bins=bins, min_high_coverage=mhc, skip_baseline_selection=skip, downsample_rate=rate)
+    okw = dict(want_estimates=True)
+    if rate > 1:
+        okw['ds_start'] = offs
+    rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, scale, prm, **okw)
+    bad = []
+    cols = [0, 1, 2, 3, 5, 6]
+    for g in range(n_genes):
+        why = []
+        if not np.array_equal(trace[g, cols], trace_o[g, cols]):
+            why.append('trace dev {0} oracle {1}'.format(trace[g, :7].tolist(), trace_o[g, :7].tolist()))
+        if flags[g] != flags_o[g]:
+            why.append('flag dev {0} oracle {1}'.format(flags[g], flags_o[g]))
+        if not why:
+            if not np.allclose(rho[g], rho_o[g], rtol=1e-8, atol=1e-10, equal_nan=True):
+                why.append('rho max abs diff {0:.3e}'.format(np.nanmax(np.abs(rho[g] - rho_o[g]))))
+            if est_o is not None and est_o[g] is not None and not np.allclose(est[g], est_o[g], rtol=1e-8, atol=1e-8, equal_nan=True):
+                why.append('estimate max abs diff {0:.3e}'.format(np.nanmax(np.abs(est[g] - est_o[g]))))
+        if why:
+            bad.append((g, kinds[g], covs[g].shape[1], why))
+    log('{0}  kernels {1}  -> {2} mismatching genes'.format(what, [n for n in names if n], len(bad)))
+    for g, kind, L, why in bad:
+        log('      gene {0} ({1}, L={2}): {3}'.format(g, kind, L, '; '.join(why)))
+    return n_genes, len(bad)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rounds', type=int, default=40)
+    ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--max-length', type=int, default=9000)
+    ap.add_argument('--out', default='')
+    args = ap.parse_args()
+    from degnorm_amd import _lib
+    from oracle import oracle
+    oracle.build()
+    fh = open(args.out, 'w') if args.out else None
+
+    def log(s):
+        print(s, flush=True)
+        if fh:
+            fh.write(s + '\n'); fh.flush()
+
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    tot = bad = 0
+    for r in range(args.rounds):
+        n, b = one_round(rng, _lib.Device, oracle, lambda s, r=r: log('[{0:3d}] '.format(r) + s if not s.startswith('      ') else s), args.max_length)
+        tot += n; bad += b
+    log('fuzz: seed {0}, {1} rounds, {2} genes, {3} mismatching, {4:.0f} s'.format(args.seed, args.rounds, tot, bad, time.time() - t0))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
