@@ -127,12 +127,75 @@ def one_round(rng, device_cls, oracle, log, budget_cols):
     return n_genes, len(bad)
 
 
+def one_chain_round(rng, oracle, log, budget_cols):
+    """The whole chain (GeneNMFOA.fit: initial pass, normalisation, outer iterations with the device-side update) against oracle.run."""
+    from collections import OrderedDict
+    from degnorm_amd.nmf import GeneNMFOA
+    from degnorm_amd import synth
+    p = int(rng.choice([2, 3, 4, 6, 8, 10, 10, 12, 13, 16, 17, 24, 33, 50, 64]))
+    rate = int(rng.choice([1, 1, 1, 40, 200]))
+    n_genes = int(rng.integers(2, 120))
+    iters = int(rng.choice([1, 2, 3, 5]))
+    T = int(rng.choice([2, 5, 12, 30]))
+    covs, kinds = [], []
+    for g in range(n_genes):
+        if rate > 1:
+            L = int(rng.integers(rate + 1, min(13 * rate, 6000) + 1))
+        else:
+            r = rng.random()
+            L = int(rng.integers(60, 400)) if r < 0.3 else int(rng.integers(400, 2500)) if r < 0.85 else int(rng.integers(2500, budget_cols))
+        kind = str(rng.choice(['plain', 'plain', 'decay', 'decay', 'holes', 'big', 'fractional', 'spike', 'empty_sample']))
+        covs.append(make_gene(rng, p, L, kind))
+        kinds.append(kind)
+    reads = np.vstack([synth.read_counts_from_coverage(c) for c in covs])
+    ds = rng.integers(0, rate, size=(iters, n_genes)).astype(np.int64) if rate > 1 else None
+    what = 'chain p={0} genes={1} rate={2} iters={3} T={4}'.format(p, n_genes, rate, iters, T)
+    kw = dict(degnorm_iter=iters, nmf_iter=T, downsample_rate=rate, min_high_coverage=2 if rate > 1 else 50)
+    hist = {}
+    try:
+        ref = oracle.run(covs, reads, ds_starts=ds, n_threads=8, history=hist, **kw)
+        ref_err = None
+    except Exception as e:                                   # the reference's own errors (e.g. a sample without reads)
+        ref, ref_err = None, type(e).__name__ + ': ' + str(e)[:80]
+    m = GeneNMFOA(degnorm_iter=iters, nmf_iter=T, downsample_rate=rate, device=0)
+    if ds is not None:
+        m.downsample_offsets = ds
+    try:
+        m.fit(OrderedDict(('g%06d' % k, c) for k, c in enumerate(covs)), reads)
+        dev_err = None
+    except Exception as e:
+        dev_err = type(e).__name__ + ': ' + str(e)[:80]
+    if ref_err or dev_err:
+        same = (ref_err is not None) and (dev_err is not None) and ref_err.split(':')[0] == dev_err.split(':')[0]
+        log('{0}  -> oracle {1} / device {2}  [{3}]'.format(what, ref_err, dev_err, 'same error class' if same else 'DIFFERENT'))
+        return n_genes, 0 if same else n_genes
+    flipped = np.zeros(n_genes, dtype=bool)
+    for i in range(iters):
+        flipped |= np.any(m.traces[i][:, [0, 1, 2, 3, 5, 6]] != hist['trace'][i][:, [0, 1, 2, 3, 5, 6]], axis=1)
+    flipped |= np.any(m.ran_baseline_selection != ref['ran_baseline_selection'], axis=1)
+    ok = ~flipped
+    rel = np.abs(m.rho - ref['rho']) / np.maximum(np.abs(ref['rho']), 1e-6)
+    rel_adj = np.abs(m.x_adj - ref['x_adj']) / np.maximum(np.abs(ref['x_adj']), 1e-300)
+    sf = float(np.max(np.abs(m.scale_factors - ref['scale_factors']) / ref['scale_factors']))
+    worst = float(rel[ok].max()) if ok.any() else 0.0
+    worst_adj = float(rel_adj[ok].max()) if ok.any() else 0.0
+    bad = int(flipped.sum()) + int(((rel > 1e-5).any(axis=1) & ok).sum())
+    log('{0}  -> flipped {1}, unflipped max rel DI {2:.1e}, adjusted counts {3:.1e}, scale factors {4:.1e}'.format(what, int(flipped.sum()), worst, worst_adj, sf))
+    for k in np.flatnonzero(flipped)[:3]:
+        for i in range(iters):
+            if np.any(m.traces[i][k, :7] != hist['trace'][i][k, :7]):
+                log('      gene {0} ({1}, L={2}) iteration {3}: trace dev {4} oracle {5}'.format(k, kinds[k], covs[k].shape[1], i + 1, m.traces[i][k, :7].tolist(), hist['trace'][i][k, :7].tolist()))
+                break
+    return n_genes, bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=40)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--max-length', type=int, default=9000)
     ap.add_argument('--out', default='')
+    ap.add_argument('--chain', action='store_true', help='whole-chain rounds (GeneNMFOA.fit vs oracle.run) instead of single baseline iterations')
     args = ap.parse_args()
     from degnorm_amd import _lib
     from oracle import oracle
@@ -148,7 +211,8 @@ def main():
     t0 = time.time()
     tot = bad = 0
     for r in range(args.rounds):
-        n, b = one_round(rng, _lib.Device, oracle, lambda s, r=r: log('[{0:3d}] '.format(r) + s if not s.startswith('      ') else s), args.max_length)
+        lg = lambda s, r=r: log('[{0:3d}] '.format(r) + s if not s.startswith('      ') else s)
+        n, b = one_chain_round(rng, oracle, lg, args.max_length) if args.chain else one_round(rng, _lib.Device, oracle, lg, args.max_length)
         tot += n; bad += b
     log('fuzz: seed {0}, {1} rounds, {2} genes, {3} mismatching, {4:.0f} s'.format(args.seed, args.rounds, tot, bad, time.time() - t0))
     return 0
