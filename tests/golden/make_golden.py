@@ -304,9 +304,9 @@ def sec_sparse():
     keep = []
     tried = 0
     t0 = time.time()
-    while len(keep) < 64 and tried < 1500:
+    while len(keep) < 80 and tried < 2500:
         tried += 1
-        p = int(rng.choice([2, 3, 4, 5, 6, 8, 10, 12, 16, 24]))
+        p = int(rng.choice([2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 33, 50]))
         rate = int(rng.choice([1, 1, 40, 200]))
         L = int(rng.integers(rate + 1, 13 * rate + 1)) if rate > 1 else int(rng.integers(20, 700))
         L = min(L, 1800)

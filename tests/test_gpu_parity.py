@@ -896,4 +896,4 @@ def test_sparse_genes_vs_reference_golden(oracle):
             np.testing.assert_allclose(rho[0], c['rho'], rtol=1e-8, atol=1e-10, err_msg=msg)
             np.testing.assert_allclose(est[0].sum(axis=1), c['est_rowsum'], rtol=1e-8, atol=1e-8, err_msg=msg)
         n += 1; n_dec += c['decoupled']
-    assert n >= 60 and n_dec >= 20
+    assert n >= 60 and n_dec >= 20                          # p = 2 .. 50: MFMA-solver bodies, the row solver (17 .. 24), mg_core (>= 25)
