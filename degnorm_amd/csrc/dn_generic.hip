@@ -206,7 +206,9 @@ constexpr int NSM_MAX = 12;                   // widest active matrix the row-wi
 constexpr int ROWS_ZSLOT = 255;               // last double of g_rows_tot, kept at 0.0 (padding lanes of the solver read it)
 
 // NSM: compiled column capacity (4, 6, 8, 10 or 12: the Gram matrix and the solver's tile shrink with it)
-template <int NSM>
+// SAFE: the repeat of a call whose result shows samples decoupled from the top block (dn_kernels.hpp, warm_start_unsafe): every solve
+// block by block.  A separate instantiation -- inside the hot one the rare path cost 32 % (17.6 against 13.3 ms per launch on config 4)
+template <int NSM, bool SAFE = false>
 __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, double *sv, double *sj,
                                                    int n, int S, int T, int first_i, int p)
 {
@@ -231,7 +233,6 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
         double theta = 0.0;
         int steps = 0, st = ST_OK;
         bool noconv = false;
-        bool cold_every_solve = false;                                  // dn_kernels.hpp, warm_start_unsafe (here: columns in blocks)
 #pragma clang loop unroll(disable)
         for (int t = -1; t < T; t++) {                                  // t = -1: SVD of x itself (nmf.py:88)
             if (t >= 0) {
@@ -260,22 +261,14 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             if (lane < NSM) tot[lane * (lane + 1) / 2 + lane] -= est.mu;   // the solver takes G - mu I
             wave_fence();
             int r;
-            if (!cold_every_solve) r = top_eig_mfma<NSM>(tot, ROWS_ZSLOT, v, theta, est, t == T - 1, g_st.max_steps);
-            else {                                                      // columns in blocks without a common sample: block by block
+            if constexpr (SAFE) {                                       // the safe repeat (k_baseline_gen decides): block by block, unshifted
                 Solver<NSM> sol;
                 sol.st = est;
                 r = solve_by_blocks<NSM>(sol, tot, ROWS_ZSLOT, v, theta, g_st.max_steps, n);
                 est = sol.st;
-            }
+            } else r = top_eig_mfma<NSM>(tot, ROWS_ZSLOT, v, theta, est, t == T - 1, g_st.max_steps);
             steps += r;
             if (r > g_st.max_steps) noconv = true;
-            if (t < 0) {
-                double vm = v[0];
-#pragma unroll
-                for (int j = 1; j < NSM; j++) vm = (j < n && v[j] < vm) ? v[j] : vm;
-                cold_every_solve = __builtin_amdgcn_readfirstlane((int) (vm < WARM_START_MIN_COMPONENT)) != 0;
-                if (cold_every_solve) est.mu = 0.0;                      // block-by-block solves run unshifted (Solver::no_shift)
-            }
             wave_fence();
         }
         if (st == ST_OK) {
@@ -454,6 +447,27 @@ __global__ __launch_bounds__(NT, DN_GEN_MINW) void k_baseline_gen(IterArgs A)
                     else if (n <= NSM_MAX) nmf_rows<12>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
 #endif
                     else nmf_gen(Fb, Ast, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+                    if (n <= NSM_MAX) {
+                        // the safe repeat (dn_kernels.hpp, warm_start_unsafe): a covered sample whose component of u is (nearly) zero is
+                        // decoupled from the block the call ended on, a solve in its step cap is most likely two blocks racing
+                        bool unsafe = g_st.status == ST_NO_CONVERGENCE;
+                        if (g_st.status == ST_OK)
+                            for (int i = 0; i < p; i++) unsafe = unsafe || (g_st.rsum[i] > 0.0 && g_st.u[i] < WARM_START_MIN_COMPONENT);
+                        if (unsafe) {
+                            __syncthreads();
+#if DN_ROWS_EXACT
+#define DN_ROWS_CASE(N) case N: nmf_rows<N, true>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p); break;
+                            switch (n) {
+                                DN_ROWS_CASE(3) DN_ROWS_CASE(4) DN_ROWS_CASE(5) DN_ROWS_CASE(6) DN_ROWS_CASE(7) DN_ROWS_CASE(8)
+                                DN_ROWS_CASE(9) DN_ROWS_CASE(10) DN_ROWS_CASE(11) DN_ROWS_CASE(12)
+                                default: nmf_rows<2, true>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p); break;
+                            }
+#undef DN_ROWS_CASE
+#else
+                            nmf_rows<12, true>(Fb, rs, sv, sj, n, S, A.T, first ? 1 : 0, p);
+#endif
+                        }
+                    }
                     if (g_st.status != ST_OK) { status = g_st.status; break; }
                     n_calls++; sum_cols += n;
                     if (first) {

@@ -93,6 +93,7 @@ def one_round(rng, device_cls, oracle, log, budget_cols):
         if rate > 1 and rng.random() < 0.7:
             dev.hint_downsample(rate)
         dev.upload(covs)
+        init = dev.ratio_svd_sums() if hasattr(dev, 'ratio_svd_sums') else None      # the initial DI pass (nmf.py:109-121) on the same upload
         kw = dict(nmf_iter=T, bins=bins, min_high_coverage=mhc, skip_baseline_selection=skip, want_estimates=True)
         if rate > 1:
             kw.update(downsample_rate=rate, ds_start=offs)
@@ -108,8 +109,15 @@ def one_round(rng, device_cls, oracle, log, budget_cols):
     rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, scale, prm, **okw)
     bad = []
     cols = [0, 1, 2, 3, 5, 6]
+    init_o = oracle.ratio_svd_batch(covs) if init is not None else None
     for g in range(n_genes):
         why = []
+        if init is not None:
+            (e_d, c_d, s_d), (e_o, c_o, s_o) = init, init_o
+            if s_d[g] != s_o[g]:
+                why.append('initial pass status dev {0} oracle {1}'.format(s_d[g], s_o[g]))
+            elif s_o[g] == 0 and not (np.allclose(c_d[g], c_o[g], rtol=1e-13) and np.allclose(e_d[g], e_o[g], rtol=1e-9, atol=1e-7 * max(1.0, float(np.max(e_o[g]))))):
+                why.append('initial pass sums: max rel diff {0:.2e}'.format(float(np.max(np.abs(e_d[g] - e_o[g]) / np.maximum(np.abs(e_o[g]), 1e-30)))))
         if not np.array_equal(trace[g, cols], trace_o[g, cols]):
             why.append('trace dev {0} oracle {1}'.format(trace[g, :7].tolist(), trace_o[g, :7].tolist()))
         if flags[g] != flags_o[g]:
