@@ -49,11 +49,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz (AMD MI355X spec)
-# tools/ubench/clock_issue.hip on the box (profiles/round2/ubench_clock_issue.txt), in-kernel clock 2.37-2.39 GHz: ONE wave
-# alone on a SIMD issues the instruction mix of a column of the pass (10 cvt + 10 mul + 30 fma + 10 max + 55 Gram fma,
-# registers only) at 4.22 cycles per instruction against the 4 of the peak above (two waves per SIMD: 3.95); a stream of
-# nothing but dependent-free fp64 FMAs issues slower (5.75, 4.4 with four waves).  The kernel runs one wave per SIMD.
-FP64_ISSUE_CYCLES_1WAVE = 4.22
+# tools/ubench/instr_cost.hip on the box (profiles/round3/ubench_instr_cost.txt): ONE wave alone on a SIMD issues every vector
+# instruction of the column body -- fp64 FMA / mul / max with any operand mix, conversions, the 32-bit AGPR moves and unpacks, even
+# back-to-back dependent FMAs -- at 4.08 cycles, against the 4 of the peak above (the 4.22 of round 2's clock_issue.hip included the
+# scalar overhead of its loop).  The kernel runs one wave per SIMD, so a moved dword costs as much as an fp64 FMA.
+FP64_ISSUE_CYCLES_1WAVE = 4.08
 ROUND = 'round3'
 REFERENCE_PY_GENES_PER_S_PER_THREAD = 0.18    # the reference itself (n_jobs = 1) on config-2-like genes, 5 iterations
 
@@ -562,8 +562,8 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
                                          'note': 'only the dominant kernel\'s genes over its launch duration (it has the chip to itself '
                                                  'for only part of that time)'},
             'issue_ceiling': {'peak': issue_peak, 'frac': tflops / issue_peak,
-                              'what': 'one wave per SIMD issues the column\'s instruction mix at {0} cycles per instruction, not 4 '
-                                      '(tools/ubench/clock_issue.hip, in-kernel clock 2.37-2.39 GHz; profiles/round2/ubench_clock_issue.txt)'
+                              'what': 'one wave per SIMD issues every vector instruction of the column body at {0} cycles, not 4, whatever '
+                                      'its kind (tools/ubench/instr_cost.hip; profiles/round3/ubench_instr_cost.txt)'
                                       .format(FP64_ISSUE_CYCLES_1WAVE)},
             'valu_issue_slots': {'wave_instructions': instr_a, 'slots_frac': instr_a * 4.0 / simd_cycles(avg_ms),
                                  'what': 'fp64 wave-instructions of the passes x 4 cycles / (sweep time x 2.4 GHz x 1024 SIMDs)'},
