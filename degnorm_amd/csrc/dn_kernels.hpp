@@ -201,7 +201,16 @@ __device__ __forceinline__ double uniform(double v)
 // registers (dn_reduce.hpp: lane l ends up with the wave total of entry bitrev6(l)), one LDS write per lane hands
 // them to the cross-wave add.
 // One round of the per-wave reduction: entries [OFF, OFF + CNT) of g, CNT <= 64, totals into dst[OFF + entry].
-template <int N, int OFF, typename VT>
+// the block total of a packed Gram entry as the solver wants it: minus the shift on the diagonal (dsel: 1 there, else 0); with the
+// Gram matrix accumulated in raw count units (RAWSC) dsel carries the entry's scale 1 / (s_a s_b), negative on the diagonal
+template <bool RAWSC>
+__device__ __forceinline__ double shift_total(double s, double d, double diag_shift)
+{
+    if constexpr (RAWSC) return fma(s, fabs(d), d < 0.0 ? -diag_shift : 0.0);
+    else return fma(-diag_shift, d, s);
+}
+
+template <int N, int OFF, typename VT, bool RAWSC = false>
 __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, int lane, double diag_shift, const double *dsel,
                                                  bool shift_here)
 {
@@ -212,21 +221,22 @@ __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, 
     double s = wave_reduce_scatter<CNT, VT>(part, lane);
     const int e = reduce_scatter_entry(lane);
     if (e < CNT) {
-        if (shift_here) s = fma(-diag_shift, dsel[OFF + e], s);
+        if (shift_here) s = shift_total<RAWSC>(s, dsel[OFF + e], diag_shift);
         dst[OFF + e] = s;
     }
-    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT>(g, dst, lane, diag_shift, dsel, shift_here);
+    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT, RAWSC>(g, dst, lane, diag_shift, dsel, shift_here);
 }
 
-template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0>    // OFF: the totals go to tot[OFF .. OFF + N)
+template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0, bool RAWSC = false>    // OFF: the totals go to tot[OFF .. OFF + N)
 __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm, double diag_shift = 0.0)
 {
+    static_assert(!RAWSC || SHIFT, "the raw-unit scale rides on the shift step");
     static_assert(OFF + N <= Smem<P, NT>::NX - 1, "xw too small");
     static_assert(!SHIFT || OFF + N <= P * (P + 1) / 2, "the shift is for the packed Gram matrix");
     constexpr int W = NT / 64;
     const int lane = lane_id(), w = wave_id();
     double *dst = ((W > 1) ? sm.xw[w] : sm.tot) + OFF;
-    wave_round_store<N, 0, VT>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1);     // ceil(N / 64) rounds
+    wave_round_store<N, 0, VT, RAWSC>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1);     // ceil(N / 64) rounds
     DN_MARK("wave_reduced");
     if constexpr (W > 1) {
         __syncthreads();
@@ -234,7 +244,7 @@ __device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm,
             double t = sm.xw[0][e];
 #pragma unroll
             for (int ww = 1; ww < W; ww++) t += sm.xw[ww][e];
-            if constexpr (SHIFT) t = fma(-diag_shift, sm.dsel[e], t);                // G - mu I for the eigen-solver
+            if constexpr (SHIFT) t = shift_total<RAWSC>(t, sm.dsel[e], diag_shift);  // G - mu I for the eigen-solver
             sm.tot[e] = t;
         }
     }
@@ -912,6 +922,7 @@ struct GeneState {
     double rho_fb[P];    // DI of max(K_start E_start, F_start)                   nmf.py:345-346, :352-353
     double sig0;         // sigma of the first call
     double inv[P];       // 1 / scale factors
+    double scl[P];       // the scale factors again (1 / inv): u_i s_i of the raw-unit pass (DN_RAW_UNITS)
     double u[P];         // outputs of the last nmf() call: top left singular vector,
     double theta;        //   sigma^2,
     double sums[2 * P + 1];   // { sum_j s_j, clamped row sums (P), row sums of Fb (P) }
@@ -950,8 +961,10 @@ typedef double __attribute__((address_space(1))) *gdouble_ptr;
 // with s = u . a (E_j sigma), so a pass costs 3 fp64 ops per element plus the p(p+1)/2 Gram products and
 // x + lambda is never re-formed (nmf.py:97).  lambda is not needed by itself anywhere.
 template <int P>
-__device__ __forceinline__ void col_update(const double (&f)[P], double (&a)[P], const double (&u)[P], double c)
+__device__ __forceinline__ void col_update(const double (&f)[P], double (&a)[P], const double (&u)[P], const double (&ur)[P], double c)
 {
+    // u: the coefficients of the dot product, ur: those of the residual -- the same vector, except in raw count units (DN_RAW_UNITS:
+    // u_i / s_i and u_i s_i)
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int i = 0; i + 1 < P; i += 2) { s0 = fma(u[i], a[i], s0); s1 = fma(u[i + 1], a[i + 1], s1); }
@@ -959,7 +972,7 @@ __device__ __forceinline__ void col_update(const double (&f)[P], double (&a)[P],
     const double s = s0 + s1;                                          // E_j * sigma = u . (x + lambda)_j
 #pragma unroll
     for (int i = 0; i < P; i++) {
-        const double res = fma(u[i], s, -f[i]);                        // est - x                       nmf.py:94
+        const double res = fma(ur[i], s, -f[i]);                       // est - x                       nmf.py:94
         a[i] = fmax(fma(-c, res, a[i]), f[i]);                         // x + max(lambda - c res, 0)    nmf.py:95-97
     }
 }
@@ -1053,6 +1066,14 @@ __device__ __forceinline__ void load_f(gF_cptr Fb, int k, const double (&inv)[P]
     load_x<P>(Fb, k, x);
 #pragma unroll
     for (int i = 0; i < P; i++) f[i] = (double) x[i] * inv[i];
+}
+
+// the counts of a column as the pass wants them: scaled (x / s_i), or left raw when the state is kept in raw units (DN_RAW_UNITS)
+template <int P, bool RAW>
+__device__ __forceinline__ void pass_counts(const float (&x)[P], const double (&inv)[P], double (&f)[P])
+{
+#pragma unroll
+    for (int i = 0; i < P; i++) f[i] = RAW ? (double) x[i] : (double) x[i] * inv[i];
 }
 
 // Spill-tier layout: blocks of 64 columns, inside a block the p rows of 64 doubles back to back.  A wave (64 consecutive
@@ -1285,6 +1306,13 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #define DN_RT_MIN_P 2            // round 3: the tier (and with it the pair class) serves every p <= 12.  Round 2 stopped at 8 ("below it a
 #endif                           // workgroup needs so few registers that several share a SIMD") -- measured on config-2-shaped genes: p = 3
                                  // +31 %, 4 +7 %, 5 +31 %, 6 +26 %, 7 +47 % genes/s (tools/p_sweep.py, profiles/round3/p_sweep.txt)
+// DN_RAW_UNITS: inside the T loop of the register-tier cohorts the state is kept in RAW count units (a~ = x + lambda / s_i instead
+// of x / s_i + lambda): the counts need no scaling multiply per element and pass (-10 of the 171 vector instructions of a
+// register-tier column at p = 10); u is handed to the pass as u_i / s_i (dot product) and u_i s_i (residual), the Gram matrix is
+// accumulated in raw units and scaled entry by entry as the block total is written (block_sum_lds), so the solver sees what it saw
+#ifndef DN_RAW_UNITS
+#define DN_RAW_UNITS 1
+#endif
 #if defined(DN_P) && DN_P >= DN_RT_MIN_P && DN_P <= DN_RT_MAX_P && !defined(DN_NO_REG_TIER)
 #define DN_REG_TIER 1
 #define DN_KERNEL_WAVES 2        // the register ALLOCATOR's budget: 512 / 2 registers (the kernel really runs one wave per SIMD)
@@ -1300,6 +1328,10 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #define DN_KERNEL_WAVES 1
 #define DN_RT_CLAIM()
 #endif
+#ifndef DN_RAW_MAX_P
+#define DN_RAW_MAX_P 11          // p = 12 (78 Gram accumulators: the tightest register budget of the tier) fails the edge-shape parity test in its pair build with raw units
+#endif
+template <int P> constexpr bool raw_units() { return DN_RAW_UNITS != 0 && DN_REG_TIER != 0 && P <= DN_RAW_MAX_P && P < DN_MG_MIN_P; }
 
 // agpr_get1<N>() / agpr_put1<N>(v): the 32-bit value held in aN.  Register names must be literal text, hence the list.
 template <int IDX> __device__ __forceinline__ int agpr_get1();
@@ -1466,6 +1498,8 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     constexpr int RT = DN_REG_TIER ? rt_cols<P, X16>() : 0;   // columns per lane held in AGPRs (register tier)
     constexpr int CS = rt_col_regs<P, X16>();              // registers per column: the state, and with X16 the packed raw counts
     constexpr int NR = RT * NT;                            // the gene's first NR columns
+    constexpr bool RAW = raw_units<P>();                   // the state of the T loop in raw count units (DN_RAW_UNITS)
+    double ud[P], ur[P];                                   // u as the pass takes it: dot-product and residual coefficients (col_update)
     const int nLe = (n < NR + nL) ? n : NR + nL;           // end of the LDS tier (absolute column); LDS slot of column k: k - NR
     const int kS0 = NR + nL;                               // first column of the spill tier
     if constexpr (P >= DN_MG_MIN_P) {
@@ -1526,8 +1560,33 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         steps += r; noconv = noconv || r > maxs;
     }
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
+    // u for the pass, in scalar registers (two-VGPR-source FMAs).  Raw units: u_i / s_i and u_i s_i, scaled per lane in the solver's
+    // iterate layout (lane group q holds v[q + 4 kb]) and broadcast from there
+    auto pass_u = [&]() {
+        if constexpr (RAW) {
+            constexpr int KB = EigState<P>::KB;
+            const int q = lane_id() >> 4;
+            double vt[KB], vh[KB];
 #pragma unroll
-    for (int i = 0; i < P; i++) u[i] = uniform(u[i]);                 // keep u in scalar registers: two-VGPR-source FMAs
+            for (int kb = 0; kb < KB; kb++) {
+                const int k = q + 4 * kb < P ? q + 4 * kb : P - 1;
+                vt[kb] = solver.st.v[kb] * g_gs.inv[k];
+                vh[kb] = solver.st.v[kb] * g_gs.scl[k];
+            }
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const double a_ = vt[i >> 2], b_ = vh[i >> 2];
+                ud[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a_), 16 * (i & 3)),
+                                         __builtin_amdgcn_readlane(__double2loint(a_), 16 * (i & 3)));
+                ur[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b_), 16 * (i & 3)),
+                                         __builtin_amdgcn_readlane(__double2loint(b_), 16 * (i & 3)));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; i++) { u[i] = uniform(u[i]); ud[i] = u[i]; ur[i] = u[i]; }
+        }
+    };
+    pass_u();
 
     static_for<0, RT>([&](auto rc) {                             // lmbda = zeros (nmf.py:90): state a = x
         constexpr int R = decltype(rc)::value;
@@ -1536,15 +1595,14 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             float xf[P];
             double f[P];
             load_x<P>(Fb, k, xf);
-#pragma unroll
-            for (int i = 0; i < P; i++) f[i] = (double) xf[i] * inv[i];
+            pass_counts<P, RAW>(xf, inv, f);
             rt_write<P, CS * R>(f);
             if constexpr (X16) rt_write_counts<P, CS * R + 2 * P>(xf);
         }
     });
     for (int k = NR + tid; k < nLe; k += NT) {
         double f[P], a[PS];
-        load_f<P>(Fb, k, inv, f);
+        { float xf[P]; load_x<P>(Fb, k, xf); pass_counts<P, RAW>(xf, inv, f); }
 #pragma unroll
         for (int i = 0; i < PS; i++) a[i] = i < P ? f[i] : 0.0;
         lds_col_write<PS>(lam + (size_t) (k - NR) * PS, a);
@@ -1584,10 +1642,12 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                     constexpr int R = decltype(rc)::value;
                     double f[P], a[P];
                     rt_read_counts<P, CS * R + 2 * P>(f);
+                    if constexpr (!RAW) {
 #pragma unroll
-                    for (int i = 0; i < P; i++) f[i] *= inv[i];
+                        for (int i = 0; i < P; i++) f[i] *= inv[i];
+                    }
                     rt_read<P, CS * R>(a);
-                    col_update<P>(f, a, u, c);
+                    col_update<P>(f, a, ud, ur, c);
                     if constexpr (G0 && R == 0) gram_set_range<P, 0, CH>(G, a); else gram_add_range<P, 0, CH>(G, a);
                     rt_write<P, CS * R>(a);
                 };
@@ -1612,11 +1672,10 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                     const int k = tid + R * NT;
                     if (k < n) {
                         double f[P], a[P];
-#pragma unroll
-                        for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
+                        pass_counts<P, RAW>(xq, inv, f);
                         if constexpr (R + 1 < RT) load_x<P>(Fb, k + NT < n ? k + NT : k, xq);
                         rt_read<P, CS * R>(a);
-                        col_update<P>(f, a, u, c);
+                        col_update<P>(f, a, ud, ur, c);
                         gram_add_range<P, 0, CH>(G, a);
                         rt_write<P, CS * R>(a);
                     }
@@ -1634,13 +1693,12 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             for (int j = 0; j < cnt; j++, k += step) {
                 double f[P], a[PS];
                 lds_col_read<PS>(lam + (size_t) (k - NR) * PS, a);
-#pragma unroll
-                for (int i = 0; i < P; i++) f[i] = (double) xq[i] * inv[i];
+                pass_counts<P, RAW>(xq, inv, f);
                 load_x<P>(Fb, j + 1 < cnt ? k + step : k, xq);      // unconditional (clamped): no branch around the loads
                 double aa[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) aa[i] = a[i];
-                col_update<P>(f, aa, u, c);
+                col_update<P>(f, aa, ud, ur, c);
                 gram_add_range<P, 0, CH>(G, aa);
 #pragma unroll
                 for (int i = 0; i < P; i++) a[i] = aa[i];
@@ -1667,8 +1725,9 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #pragma clang loop unroll(disable)
             for (int j = 0; j < cnt; j++, k += step) {
                 double f[P], a[P];
+                pass_counts<P, RAW>(xn, inv, f);
 #pragma unroll
-                for (int i = 0; i < P; i++) { f[i] = (double) xn[i] * inv[i]; a[i] = t > 0 ? an[i] : f[i]; }
+                for (int i = 0; i < P; i++) a[i] = t > 0 ? an[i] : f[i];
                 if (j + 1 < cnt) {
                     load_x<P>(Fb, k + step, xn);
                     if (t > 0) {
@@ -1676,7 +1735,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                         for (int i = 0; i < P; i++) an[i] = *(spill_ptr<P>(Lg, k + step) + i * 64);
                     }
                 }
-                col_update<P>(f, a, u, c);
+                col_update<P>(f, a, ud, ur, c);
                 gram_add_range<P, 0, CH>(G, a);
 #pragma unroll
                 for (int i = 0; i < P; i++) *(spill_ptr<P>(Lg, k) + i * 64) = a[i];
@@ -1695,7 +1754,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         DN_T1(0);
 #endif
         }
-        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
+        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED, 0, RAW>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
         DN_MARK("reduced");
         // later sweeps (p >= 16): the remaining Gram entries from the updated state, read-only
         static_for<1, SW>([&](auto qc) {
@@ -1723,13 +1782,23 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             block_sum_lds<NQ, P, NT, gram_t, Solver<P>::SHIFTED, Q * CH>(Gq, g_sm, solver.shift());
         });
         { DN_T0();
-        const int r = SAFE ? solve_by_blocks<P>(solver, sm.tot, Smem<P, NT>::ZSLOT, u, theta, maxs)
-                           : solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, t == T - 1, maxs);   // sigma^2 is only read after the last solve
+        // raw units: the pass takes u from the solver's iterate (pass_u); the broadcast copy is rebuilt once, after the loop
+        double u_unused[P];
+        double (&us_)[P] = RAW ? u_unused : u;
+        const int r = SAFE ? solve_by_blocks<P>(solver, sm.tot, Smem<P, NT>::ZSLOT, us_, theta, maxs)
+                           : solver.run(sm.tot, Smem<P, NT>::ZSLOT, us_, theta, t == T - 1, maxs);   // sigma^2 is only read after the last solve
         steps += r; noconv = noconv || r > maxs;
-#pragma unroll
-        for (int i = 0; i < P; i++) u[i] = uniform(u[i]);
+        pass_u();
         DN_MARK("solved");
         DN_T1(2);
+        }
+    }
+    if constexpr (RAW) {
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const double t_ = solver.st.v[i >> 2];
+            u[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t_), 16 * (i & 3)),
+                                    __builtin_amdgcn_readlane(__double2loint(t_), 16 * (i & 3)));
         }
     }
     }   // narrow cohorts
@@ -1738,11 +1807,18 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
 #ifdef DN_STAMP
     const long long t_fin0 = __builtin_amdgcn_s_memtime();
 #endif
+    // raw units: the T loop did not need the scale factors; they come back from LDS here instead of sitting in 20 scalar registers
+    // through the loop (next to the two coefficient sets of the pass that made the allocator spill scalars every iteration)
+    double invf[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) invf[i] = RAW ? uniform(g_gs.inv[i]) : inv[i];
     double acc[2 * P + 1];
 #pragma unroll
     for (int i = 0; i < 2 * P + 1; i++) acc[i] = 0.0;
-    auto fin = [&](int k, const double (&f)[P], const double (&l0)[P]) {
-        double s, r;
+    auto fin = [&](int k, const double (&f)[P], const double (&l_)[P]) {
+        double s, r, l0[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) l0[i] = RAW ? l_[i] * invf[i] : l_[i];        // raw-unit state -> x / s + lambda
         col_final<P>(f, l0, u, first, acc, s, r);
         rs[k] = r;
         if (first) sv[k] = s;
@@ -1755,8 +1831,8 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             if constexpr (X16) {
                 rt_read_counts<P, CS * R + 2 * P>(f);
 #pragma unroll
-                for (int i = 0; i < P; i++) f[i] *= inv[i];
-            } else load_f<P>(Fb, k, inv, f);
+                for (int i = 0; i < P; i++) f[i] *= invf[i];
+            } else load_f<P>(Fb, k, invf, f);
             rt_read<P, CS * R>(l);
             fin(k, f, l);
         }
@@ -1767,7 +1843,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     for (int k = NR + tid; k < n; k += NT) {
         double f[P], l[P];
 #pragma unroll
-        for (int i = 0; i < P; i++) f[i] = (double) xqf[i] * inv[i];
+        for (int i = 0; i < P; i++) f[i] = (double) xqf[i] * invf[i];
         load_x<P>(Fb, k + NT < n ? k + NT : k, xqf);
         if (k < nLe) {
             double al[PS];
@@ -1866,13 +1942,19 @@ __global__ __launch_bounds__(NT * DN_UNITS, DN_KERNEL_WAVES) void k_baseline(Ite
     double *rs = sv + S;                                              // residual profile               [S]
     double *rtsave = rs + 2 * (size_t) S;                             // caller's AGPRs during an nmf() call  [RT * P][NT]
     DN_RT_CLAIM();
-    if (tid < P) gs.inv[tid] = A.inv_scale[tid];
+    if (tid < P) { gs.inv[tid] = A.inv_scale[tid]; gs.scl[tid] = 1.0 / A.inv_scale[tid]; }
     if (tid == 0) gs.max_steps = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
     for (int t = tid; t < Smem<P, NT>::NX; t += NT) {                  // constants of the eigen-solver (top_eig_mfma)
         bool diag = false;
+        int ra = 0, rb = 0;                                             // packed entry t = (ra, rb), rb <= ra
 #pragma unroll
-        for (int i = 0; i < P; i++) diag = diag || (t == i * (i + 1) / 2 + i);
-        sm.dsel[t] = diag ? 1.0 : 0.0;
+        for (int i = 0; i < P; i++) {
+            diag = diag || (t == i * (i + 1) / 2 + i);
+            if (t >= i * (i + 1) / 2) { ra = i; rb = t - i * (i + 1) / 2; }
+        }
+        if constexpr (raw_units<P>())                                   // raw-unit Gram totals: the entry's scale, negative on the diagonal (shift_total)
+            sm.dsel[t] = (t < P * (P + 1) / 2) ? (diag ? -1.0 : 1.0) * A.inv_scale[ra] * A.inv_scale[rb < P ? rb : 0] : 0.0;
+        else sm.dsel[t] = diag ? 1.0 : 0.0;
         if (t == Smem<P, NT>::ZSLOT) sm.tot[t] = 0.0;
     }
 
