@@ -1329,7 +1329,9 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #define DN_RT_CLAIM()
 #endif
 #ifndef DN_RAW_MAX_P
-#define DN_RAW_MAX_P 11          // p = 12 (78 Gram accumulators: the tightest register budget of the tier) fails the edge-shape parity test in its pair build with raw units
+#define DN_RAW_MAX_P 11          // p = 12 stays in scaled units: with raw units its pair build fails the edge-shape parity test on genes that fill the
+                                 // register tier (the coefficients broadcast from the scaled iterate come out wrong there -- the plain form, u from the
+                                 // solver times the factors from LDS, passes; explicit wait states change nothing; not understood, so not shipped)
 #endif
 template <int P> constexpr bool raw_units() { return DN_RAW_UNITS != 0 && DN_REG_TIER != 0 && P <= DN_RAW_MAX_P && P < DN_MG_MIN_P; }
 
@@ -2080,6 +2082,9 @@ __global__ __launch_bounds__(NT * DN_UNITS, DN_KERNEL_WAVES) void k_baseline(Ite
                         // with block-by-block solves
                         const int st_call = __builtin_amdgcn_readfirstlane(gs.status);
                         bool unsafe = st_call == ST_NO_CONVERGENCE;
+#ifdef DN_FORCE_SAFE                                                        // diagnostic: every call is repeated by the safe path
+                        unsafe = unsafe || st_call == ST_OK;
+#endif
                         if (st_call == ST_OK) {
 #pragma unroll
                             for (int i = 0; i < P; i++) unsafe = unsafe || (gs.u[i] < WARM_START_MIN_COMPONENT);
