@@ -3,7 +3,7 @@ Static instruction budget of one inner NMF-OA iteration, from the ISA of a diagn
 `; DN_MARK <name>` comment lines, csrc/dn_kernels.hpp).  For every nmf() body (the four instantiations of nmf_body inside
 nmf_call) it lists, per region of the T loop, the instructions by kind -- vector ALU (fp64 arithmetic, AGPR moves, conversions,
 cross-lane moves, other), matrix, LDS, global / scratch, scalar -- and prices the region at the measured single-wave issue cadence
-(tools/ubench/clock_issue.hip: 4.22 cycles per vector instruction of this mix, 64 cycles per v_mfma_f64_16x16x4).
+(tools/ubench/instr_cost.hip: 4.08 cycles per vector instruction of any kind, 64 cycles per v_mfma_f64_16x16x4).
 usage: python tools/isa_regions.py <p> <nt> [pair]      (compiles csrc/dn_inst.hip itself; no GPU needed)
 """
 import os, re, subprocess, sys, tempfile
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from degnorm_amd import build
 
-CADENCE, MFMA_CYCLES = 4.22, 64.0
+CADENCE, MFMA_CYCLES = 4.08, 64.0          # tools/ubench/instr_cost.hip: every vector instruction, one wave per SIMD
 
 
 def kind(op):
