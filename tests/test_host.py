@@ -240,3 +240,36 @@ def test_register_tier_registers_are_private(tier_isa, p, nt):
     nfv = int(re.search(r'\.amdhsa_next_free_vgpr (\d+)\b', kern[:4000]).group(1))
     acc = int(re.search(r'\.amdhsa_accum_offset (\d+)\b', kern[:4000]).group(1))
     assert nfv - acc == 256 and nfv > 256 and acc <= 256
+
+
+def test_pass_of_the_on_chip_body_has_no_scratch_or_scalar_spill_traffic(tmp_path):
+    """
+    A static guard for the hot loop: at one wave per SIMD a scratch reload inside the T loop costs about 1 % of
+    config 2's sweep (measured twice in round 3), and the allocator puts one there at the slightest provocation.  The pass of the
+    on-chip body of nmf_call<10, *> -- register tier and LDS tier, between the iter_begin and pass_end marks of a -DDN_MARKS build --
+    must contain no scratch access and no v_writelane (scalar spill), and its register tier the 161 vector instructions per column
+    of the raw-unit pass (1 610 for the ten columns).
+    """
+    import re
+    import subprocess
+    from degnorm_amd import build
+    src = os.path.join(ROOT, 'degnorm_amd', 'csrc', 'dn_inst.hip')
+    for nt, extra in ((128, []), (64, ['-DDN_PAIR=1'])):
+        out = str(tmp_path / 'marks_{0}.s'.format(nt))
+        cmd = [build._hipcc()] + build.FLAGS + build.SCHED + build.EXTRA + ['-DDN_P=10', '-DDN_NT={0}'.format(nt), '-DDN_MARKS'] + extra + \
+              ['-S', '--cuda-device-only', src, '-o', out]
+        subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        text = open(out).read()
+        fn = text[text.index('_ZN2dn8nmf_callILi10ELi{0}ELb0E'.format(nt)):]
+        fn = fn[:fn.index('.Lfunc_end')].split('\n')
+        marks = [(i, re.search(r'DN_MARK (\w+)', l).group(1)) for i, l in enumerate(fn) if 'DN_MARK' in l]
+        i0 = next(i for i, m in marks if m == 'iter_begin')                    # body 0 = the on-chip body
+        names = [m for i, m in marks if i >= i0][:5]
+        assert names[:4] == ['iter_begin', 'zeroed', 'reg_tier', 'lds_tier'] and names[4] == 'pass_end', names
+        i_reg = next(i for i, m in marks if i > i0 and m == 'reg_tier')
+        i_lds = next(i for i, m in marks if i > i_reg and m == 'lds_tier')
+        i_end = next(i for i, m in marks if i > i_lds and m == 'pass_end')
+        ops = [l.strip().split()[0] for l in fn[i0:i_end] if l.startswith('\t') and l.strip() and l.strip()[0] not in '.;']
+        assert not [o for o in ops if o.startswith('scratch_') or o == 'v_writelane_b32'], 'spill traffic in the pass (NT = %d)' % nt
+        reg_ops = [l.strip().split()[0] for l in fn[i_reg:i_lds] if l.startswith('\t') and l.strip() and l.strip()[0] not in '.;']
+        assert sum(o.startswith('v_') for o in reg_ops) == 1610
