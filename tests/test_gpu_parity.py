@@ -4,6 +4,7 @@ and against the golden vectors generated from the real reference.  Tolerance: BA
 scores within 1e-5 relative; the device computes in float64 on float32-stored integer counts, so the
 tests hold it to RTOL = 1e-9 (and exact branch traces).
 """
+import os
 import numpy as np
 import pytest
 
@@ -897,3 +898,26 @@ def test_sparse_genes_vs_reference_golden(oracle):
             np.testing.assert_allclose(est[0].sum(axis=1), c['est_rowsum'], rtol=1e-8, atol=1e-8, err_msg=msg)
         n += 1; n_dec += c['decoupled']
     assert n >= 60 and n_dec >= 20                          # p = 2 .. 50: MFMA-solver bodies, the row solver (17 .. 24), mg_core (>= 25)
+
+
+def test_randomised_differential_rounds(oracle):
+    """
+    tools/fuzz_parity.py as a test: 30 seeded rounds of random sample counts (2 .. 64), lengths, depth regimes, pathological structure
+    (empty samples, empty stretches, counts beyond 16 bits, fractional coverage, strong 3' decay, rank 1, one very deep base), random
+    scale factors, nmf_iter, bins, min_high_coverage and down-sampling; the initial pass and one baseline iteration against the
+    oracle, branch trace and flags exact, DI and estimates to 1e-8.  The generator kind with exact ties between bin means
+    (piecewise-constant small integers: decided by summation order) is left out.
+    """
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_parity
+    from degnorm_amd import _lib
+    rng = np.random.default_rng(20261004)
+    kinds = [k for k in fuzz_parity.KINDS if k != 'steps']
+    lines, genes, bad = [], 0, 0
+    for r in range(30):
+        n, b = fuzz_parity.one_round(rng, _lib.Device, oracle, lines.append, 6000, kinds_menu=kinds)
+        genes += n
+        bad += b
+    assert genes > 800
+    assert bad == 0, '\n'.join(l for l in lines if 'mismatching' in l and not l.rstrip().endswith('-> 0 mismatching genes') or l.startswith('      '))

@@ -66,7 +66,7 @@ def make_gene(rng, p, L, kind):
 KINDS = ['plain', 'plain', 'decay', 'decay', 'empty_sample', 'holes', 'steps', 'big', 'fractional', 'rank1', 'spike']
 
 
-def one_round(rng, device_cls, oracle, log, budget_cols):
+def one_round(rng, device_cls, oracle, log, budget_cols, kinds_menu=None):
     p = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 11, 12, 13, 14, 15, 16, 17, 19, 24, 32, 33, 47, 50, 64]))
     rate = int(rng.choice([1, 1, 1, 1, 40, 200, 500]))
     n_genes = int(rng.integers(1, 90))
@@ -77,7 +77,7 @@ def one_round(rng, device_cls, oracle, log, budget_cols):
         else:
             r = rng.random()
             L = int(rng.integers(1, 130)) if r < 0.15 else int(rng.integers(130, 2500)) if r < 0.8 else int(rng.integers(2500, budget_cols))
-        kind = str(rng.choice(KINDS))
+        kind = str(rng.choice(kinds_menu or KINDS))
         covs.append(make_gene(rng, p, L, kind))
         kinds.append(kind)
     scale = np.exp(rng.uniform(-1.2, 1.2, p)) if rng.random() < 0.5 else np.linspace(0.9, 1.15, p)
