@@ -451,8 +451,11 @@ __global__ __launch_bounds__(NT, DN_GEN_MINW) void k_baseline_gen(IterArgs A)
                         // the safe repeat (dn_kernels.hpp, warm_start_unsafe): a covered sample whose component of u is (nearly) zero is
                         // decoupled from the block the call ended on, a solve in its step cap is most likely two blocks racing
                         bool unsafe = g_st.status == ST_NO_CONVERGENCE;
-                        if (g_st.status == ST_OK)
-                            for (int i = 0; i < p; i++) unsafe = unsafe || (g_st.rsum[i] > 0.0 && g_st.u[i] < WARM_START_MIN_COMPONENT);
+                        if (g_st.status == ST_OK) {                     // one sample per lane, one ballot (every wave sees all p <= 64 samples)
+                            const int l = threadIdx.x & 63;
+                            const bool mine = l < p && g_st.rsum[l] > 0.0 && g_st.u[l] < WARM_START_MIN_COMPONENT;
+                            unsafe = __ballot(mine) != 0ull;
+                        }
                         if (unsafe) {
                             __syncthreads();
 #if DN_ROWS_EXACT
