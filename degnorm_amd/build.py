@@ -30,9 +30,20 @@ EXTRA = ['-D' + d for d in os.environ.get('DN_DEFINES', '').split() if d]   # e.
 for _k in ('DN_RT_MIN_P', 'DN_RT_MAX_P'):             # the same bounds reach the kernels that PAIR_P_LIST was derived from
     if _k in os.environ:
         EXTRA.append('-D{0}={1}'.format(_k, int(os.environ[_k])))
-# kernel translation units: the max-ILP machine scheduler places the independent fp64 operations of the inner pass
-# better than the default (occupancy-driven) one for this one-wave-per-SIMD kernel: +0.7 % on config 2
-SCHED = os.environ.get('DN_HIPCC_FLAGS', '-mllvm -amdgpu-sched-strategy=max-ilp').split()
+# kernel translation units: machine-scheduler strategy (DN_HIPCC_FLAGS).  Round 2 shipped -mllvm -amdgpu-sched-strategy=max-ilp
+# (+0.7 % on config 2 then); with the raw-unit pass of round 3 the default scheduler is the faster one (283.7 against 285.8-286.3 ms
+# per sweep on one box; iterative-minreg 302.6, iterative-ilp crashes the compiler on these units)
+SCHED = os.environ.get('DN_HIPCC_FLAGS', '').split()
+MAX_ILP = ['-mllvm', '-amdgpu-sched-strategy=max-ilp']
+
+
+def sched_flags(p):
+    """Scheduler flags of the translation units of sample count p: the default scheduler for the register-tier cohorts with the
+    raw-unit pass (p = 3 .. 12: +2 ... +4.6 % genes/s per outer iteration, tools/p_sweep.py), max-ILP elsewhere (p = 2: +1.5 %,
+    p = 13: +0.7 %, p = 16: +2.5 % with it).  DN_HIPCC_FLAGS overrides both."""
+    if 'DN_HIPCC_FLAGS' in os.environ:
+        return SCHED
+    return [] if 3 <= p <= 12 else MAX_ILP
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on',
          '-Wall', '-Wno-unused-function']
 
@@ -73,12 +84,12 @@ def build_library(force=False, verbose=False):
             o = os.path.join(OBJ, 'dn_inst_p{0}_nt{1}.o'.format(p, nt))
             objs.append(o)
             if force or _newer(o, [inst] + hdr):
-                jobs.append([hipcc] + FLAGS + SCHED + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt), '-c', inst, '-o', o])
+                jobs.append([hipcc] + FLAGS + sched_flags(p) + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(nt), '-c', inst, '-o', o])
     for p in PAIR_P_LIST:
         o = os.path.join(OBJ, 'dn_inst_p{0}_pair.o'.format(p))
         objs.append(o)
         if force or _newer(o, [inst] + hdr):
-            jobs.append([hipcc] + FLAGS + SCHED + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT=64', '-DDN_PAIR=1', '-c', inst, '-o', o])
+            jobs.append([hipcc] + FLAGS + sched_flags(p) + EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT=64', '-DDN_PAIR=1', '-c', inst, '-o', o])
     gen = os.path.join(CSRC, 'dn_generic.hip')
     for gnt in (256, 64):       # general run-time-p family / one-wavefront-per-gene family (down-sampled regime)
         o_gen = os.path.join(OBJ, 'dn_generic_nt{0}.o'.format(gnt))

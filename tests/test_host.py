@@ -145,7 +145,7 @@ def _tier_variants():
 @pytest.fixture(scope='module')
 def tier_isa(tmp_path_factory):
     """ISA of every shipped register-tier translation unit (all p of build.PAIR_P_LIST x {wide, narrow, pair}), compiled in
-    parallel with exactly the flags build.py uses (FLAGS + SCHED + EXTRA)."""
+    parallel with exactly the flags build.py uses (FLAGS + sched_flags(p) + EXTRA)."""
     import subprocess
     from concurrent.futures import ThreadPoolExecutor
     from degnorm_amd import build
@@ -155,7 +155,7 @@ def tier_isa(tmp_path_factory):
     def compile_one(v):
         p, nt = v
         out = str(d / 'k_p{0}_{1}.s'.format(p, 'pair' if nt < 0 else nt))
-        cmd = [build._hipcc()] + build.FLAGS + build.SCHED + build.EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(abs(nt))] + \
+        cmd = [build._hipcc()] + build.FLAGS + build.sched_flags(p) + build.EXTRA + ['-DDN_P={0}'.format(p), '-DDN_NT={0}'.format(abs(nt))] + \
               (['-DDN_PAIR=1'] if nt < 0 else []) + ['-S', '--cuda-device-only', src, '-o', out]
         subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         return v, out
@@ -256,7 +256,7 @@ def test_pass_of_the_on_chip_body_has_no_scratch_or_scalar_spill_traffic(tmp_pat
     src = os.path.join(ROOT, 'degnorm_amd', 'csrc', 'dn_inst.hip')
     for nt, extra in ((128, []), (64, ['-DDN_PAIR=1'])):
         out = str(tmp_path / 'marks_{0}.s'.format(nt))
-        cmd = [build._hipcc()] + build.FLAGS + build.SCHED + build.EXTRA + ['-DDN_P=10', '-DDN_NT={0}'.format(nt), '-DDN_MARKS'] + extra + \
+        cmd = [build._hipcc()] + build.FLAGS + build.sched_flags(10) + build.EXTRA + ['-DDN_P=10', '-DDN_NT={0}'.format(nt), '-DDN_MARKS'] + extra + \
               ['-S', '--cuda-device-only', src, '-o', out]
         subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         text = open(out).read()

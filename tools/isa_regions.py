@@ -31,7 +31,7 @@ def main():
     p, nt = int(sys.argv[1]), int(sys.argv[2])
     pair = len(sys.argv) > 3 and sys.argv[3] == 'pair'
     out = os.path.join(tempfile.mkdtemp(), 'k.s')
-    cmd = [build._hipcc()] + build.FLAGS + build.SCHED + build.EXTRA + ['-DDN_P=%d' % p, '-DDN_NT=%d' % nt, '-DDN_MARKS'] + (['-DDN_PAIR=1'] if pair else []) + \
+    cmd = [build._hipcc()] + build.FLAGS + build.sched_flags(p) + build.EXTRA + ['-DDN_P=%d' % p, '-DDN_NT=%d' % nt, '-DDN_MARKS'] + (['-DDN_PAIR=1'] if pair else []) + \
           ['-S', '--cuda-device-only', os.path.join(ROOT, 'degnorm_amd', 'csrc', 'dn_inst.hip'), '-o', out]
     subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     text = open(out).read()
