@@ -229,7 +229,7 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
         }
         if (lane == 0) tot[ROWS_ZSLOT] = 0.0;
         const double c = 1.0 / sqrt((double) T);                        // nmf.py:91
-        EigState<NSM> est;
+        Solver<NSM> sol;                                                // carried solver state (iterate, scale, shift)
         double theta = 0.0;
         int steps = 0, st = ST_OK;
         bool noconv = false;
@@ -256,17 +256,14 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
 #pragma unroll
             for (int i = 0; i < NSM; i++) tr += tot[i * (i + 1) / 2 + i];
             if (!(tr > 0.0)) { st = ST_ARPACK; break; }
-            if (t < 0) eig_state_cold<NSM>(est, tr);
+            if (t < 0) sol.cold(tr, v);
             wave_fence();
-            if (lane < NSM) tot[lane * (lane + 1) / 2 + lane] -= est.mu;   // the solver takes G - mu I
+            if (lane < NSM) tot[lane * (lane + 1) / 2 + lane] -= sol.shift();   // the solver takes G - mu I
             wave_fence();
             int r;
             if constexpr (SAFE) {                                       // the safe repeat (k_baseline_gen decides): block by block, unshifted
-                Solver<NSM> sol;
-                sol.st = est;
                 r = solve_by_blocks<NSM>(sol, tot, ROWS_ZSLOT, v, theta, g_st.max_steps, n);
-                est = sol.st;
-            } else r = top_eig_mfma<NSM>(tot, ROWS_ZSLOT, v, theta, est, t == T - 1, g_st.max_steps);
+            } else r = sol.run(tot, ROWS_ZSLOT, v, theta, t == T - 1, g_st.max_steps, t < 0);
             steps += r;
             if (r > g_st.max_steps) noconv = true;
             wave_fence();

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "dn_reduce.hpp"
+#include "dn_dpp_ops.hpp"
 
 // Measured dead ends are recorded in DESIGN.md (section 4, "tried and not kept"), not kept here as compile-time branches:
 // non-temporal spill accesses, fp32 Gram accumulators, raw-count-units state, a lane-major tier save area, the register
@@ -295,6 +296,13 @@ __device__ __forceinline__ double wave_sum1(double v)
     return v;
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
+template <int I, int I1, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < I1) { f(std::integral_constant<int, I>{}); static_for<I + 1, I1>(f); }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Top eigenpair of the symmetric PSD p x p matrix G (packed lower triangle, idx(i,j) = i(i+1)/2 + j).
 // Shifted power iteration, warm-started from u, run by every lane on identical data until
@@ -542,6 +550,154 @@ __device__ __forceinline__ int top_eig_mfma(const double *tot, int zslot, double
     return conv ? (steps < maxs ? steps + 1 : maxs) : maxs + 1;         // > maxs: left through the step cap
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the same eigenpair by a warm-started, shifted power iteration on the vector pipe, lane = row, with the iterate
+// broadcast INSIDE the multiply: gfx90a+ has DPP forms of two fp64 instructions, v_fmac_f64 and v_mov_b64, restricted to
+// row_newbcast:j ("every lane of a 16-lane row reads lane j of the row").  With row r of H = (G - mu I) sc in the registers of
+// lane r (every 16-lane row of the wave keeps its own copy of the matrix, p <= 16), one power step is p instructions
+//     y_r += bcast_j(v) * H[r][j]          v_fmac_f64_dpp acc, v, h_j row_newbcast:j          (dn_dpp_ops.hpp, generated)
+// and leaves y distributed as v was -- no v_readlane, no LDS, no matrix instruction; a dot product over the rows costs the same p
+// instructions (bcast_j(a b) * 1.0).  What decides the design (tools/ubench/solver_instr_cost.hip, solver_ab.hip; profiles/round4):
+// at one wave per SIMD EVERY instruction -- vector, scalar, s_nop -- takes a 4-cycle issue slot (v_fmac_f64_dpp too: 4.08 cycles,
+// also as a dependent chain; fp64 rcp / rsq / sqrt 16; v_permlane32_swap 8), so a solve is priced by its instruction COUNT.  The
+// squaring solver of rounds 1-3 spends 12 chained 64-cycle MFMAs + ~220 vector + ~100 scalar instructions whatever the matrix
+// (2 286 cycles warm); config 2's matrices need 5.0 plain power steps per warm solve on average (2 ... 10; numpy restatement of the
+// T loop with this stopping rule), i.e. ~5 x 12 instructions of stepping.
+// Schedule of a warm solve: k0 "blind" steps without normalisation (k0 follows what the previous solves of the call needed),
+// normalise (u_a), one step, normalise (u_b) and measure d2 = |u_b - u_a|^2 ~ |e_a|^2.  u_b's error is rho |e_a| with rho the
+// contraction ratio of the shifted matrix; rho^2 is MEASURED whenever a solve looks twice (d2 of consecutive looks: the cold solve of
+// a call always does, a solve that had to continue does, and every 8th solve is made to by looking one step early) and carried to the
+// solves in between; stop at 4 d2 rho^2 <= 1e-26, i.e. ~1e-13 like the other solvers, the 4 being the margin for rho's drift.
+// Shift and scale (mu = mean of the non-dominant eigenvalues, sc = 1 / (theta - mu)) are set by the call's cold solve and kept for
+// its T warm solves: they only steer convergence, and refreshing them costs a trace reduction per solve.
+// Every lane of every wave runs the same instructions on the same bits: the result is wave-uniform.
+// ---------------------------------------------------------------------------------------------------
+template <int P>
+struct EigStateD {
+    double vl;           // component (lane & 15) of the iterate (unit vector; 0 in the lanes of rows >= P)
+    double sc;           // ~ 1 / (theta - mu): un-normalised steps keep the iterate's length
+    double mu;           // shift in the units of G (0: none); the caller subtracts it from the diagonal in LDS
+    double rho2;         // contraction of d2 per step, as last measured (1: not yet)
+    int k0;              // blind steps of the next solve
+    int age;             // solves since rho2 was measured
+};
+
+template <int P>
+__device__ __forceinline__ void eig_state_cold(EigStateD<P> &st, double tr)
+{
+    st.vl = (lane_id() & 15) < P ? 1.0 / sqrt((double) P) : 0.0;
+    st.sc = __builtin_amdgcn_rcp(tr);
+    st.mu = 0.0;
+    st.rho2 = 1.0;
+    st.k0 = 0;
+    st.age = 0;
+}
+
+// a condition every lane evaluates on identical bits, as a scalar (the branch on it is s_cbranch_scc, not an exec mask)
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
+template <int P>
+__device__ __forceinline__ double bcast_lane(double t, int i)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), i), __builtin_amdgcn_readlane(__double2loint(t), i));
+}
+
+constexpr int EIG_RHO_MAX_AGE = 8;
+
+// Same contract as top_eig_mfma: tot holds G - st.mu I (packed, plus a zero at zslot); u the unit top eigenvector (broadcast),
+// theta the eigenvalue of G -- the exact Rayleigh quotient when asked for (the last solve of a call), an estimate after a cold
+// solve (it sets shift and scale), untouched otherwise.  COLD: the first solve of an nmf() call.
+// ss (diagnostics, tools/ubench/solver_ab.hip): cycles per phase { load, blind steps, first normalisation, looks, epilogue }
+template <int P, bool STAMP = false>
+__device__ __forceinline__ int top_eig_dpp(const double *tot, int zslot, double (&u)[P], double &theta, EigStateD<P> &st,
+                                           bool exact_theta, bool cold, int maxs = EIG_MAX_STEPS_DEFAULT, long long *ss = nullptr)
+{
+    static_assert(P <= 16, "one row of the matrix per lane of a 16-lane DPP row");
+    long long t_last = 0;
+    if constexpr (STAMP) t_last = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);                             // the clock read stays where it is written
+            const long long t = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            ss[slot] += t - t_last; t_last = t;
+        }
+    };
+    const int r = lane_id() & 15;
+    const double sc = st.sc, mu = st.mu;
+    double Hr[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const int a = r > j ? r : j, b = r > j ? j : r;
+        Hr[j] = tot[r < P ? a * (a + 1) / 2 + b : zslot] * sc;            // rows >= P are zero and stay zero
+    }
+    DN_MARK("solver_loaded");
+    double v = st.vl;
+    const int k0 = __builtin_amdgcn_readfirstlane(st.k0);
+    const int age = __builtin_amdgcn_readfirstlane(st.age);
+    const bool probe = age >= EIG_RHO_MAX_AGE && k0 > 0;                  // look one step early, and twice: rho^2 is measured again
+    const int kb = k0 - (probe ? 1 : 0);
+    int steps = kb;
+    stamp(0);
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < kb; k++) v = dpp_matvec<P>(Hr, v);                // the length stays ~1: sc ~ 1 / (theta - mu)
+    stamp(1);
+    double n2 = dpp_rowdot<P>(v, v);
+    if (!wave_any(n2 > 0.0)) { theta = 0.0; return steps + 1; }
+    double ua = v * rsqrt_newton(n2);
+    double rho2 = st.rho2;
+    double d2_prev = 0.0, d2 = 0.0, ylen = 1.0;
+    int extra = 0;                                                         // looks beyond the first
+    bool conv = false;
+    stamp(2);
+    for (;;) {
+        const double y = dpp_matvec<P>(Hr, ua);
+        steps++;
+        n2 = dpp_rowdot<P>(y, y);
+        if (!wave_any(n2 > 0.0)) { theta = 0.0; return steps; }
+        const double inv = rsqrt_newton(n2);
+        ylen = n2 * inv;                                                   // |H u_a| ~ (theta - mu) sc
+        const double ub = y * inv;
+        const double d = ub - ua;
+        d2 = dpp_rowdot<P>(d, d);
+        ua = ub;
+        if (extra > 0) {                                                   // a second look: the contraction, measured (the floor keeps a
+            const double m = d2 * __builtin_amdgcn_rcp(d2_prev);           // difference of round-off from passing for fast convergence)
+            rho2 = m > 1e-8 ? m : 1e-8;
+        }
+        conv = wave_any((d2 <= 1e-26) | (4.0 * d2 * rho2 <= 1e-26)) && !(probe && extra == 0);
+        if (conv || steps >= maxs) break;
+        d2_prev = d2;
+        extra++;
+    }
+    stamp(3);
+    DN_MARK("solver_checked");
+#pragma unroll
+    for (int i = 0; i < P; i++) u[i] = bcast_lane<P>(ua, i);
+    if (exact_theta) theta = dpp_rowdot<P>(dpp_matvec<P>(Hr, ua), ua) / sc + mu;     // Rayleigh quotient u^T (G - mu I) u + mu
+    else if (cold) theta = fma(ylen, __builtin_amdgcn_rcp(sc), mu);
+    if (cold) {                                                            // shift and scale of this call's warm solves
+        const double dgl = tot[r < P ? r * (r + 1) / 2 + r : zslot];
+        const double tr = fma((double) P, mu, dpp_rowdot<P>(dgl, 1.0));
+        const double mn = (tr - theta) * (1.0 / (double) (P > 1 ? P - 1 : 1));
+        const double mu_n = (theta > 0.0 && mn > 0.0 && mn < 0.5 * theta) ? mn : 0.0;
+        st.mu = mu_n;
+        st.sc = __builtin_amdgcn_rcp(theta - mu_n);
+    }
+    st.vl = ua;
+    st.rho2 = rho2;
+    st.age = extra > 0 ? 0 : age + 1;
+    // the next solve takes one blind step less when this one converged with a whole step to spare (4 d2_(k-1) rho^2 = 4 d2 <= 1e-26,
+    // with a margin of 4), and as many more as this one needed looks beyond its first
+    {
+        const bool spare = extra == 0 && wave_any(16.0 * d2 <= 1e-26);
+        const int kn = kb + extra - (spare ? 1 : 0);
+        st.k0 = kn < 0 ? 0 : (kn > 24 ? 24 : kn);
+    }
+    stamp(4);
+    return conv ? (steps < maxs ? steps + 1 : maxs) : maxs + 1;           // > maxs: left through the step cap
+}
+
 // Sample counts above 16 (more than one MFMA tile): shifted power iteration with the matrix distributed by rows --
 // lane l keeps row l of G, computes one component of G v per step, v_readlane broadcasts the p components.  Two
 // unnormalised steps between convergence checks; the check predicts the current error from the contraction between
@@ -713,25 +869,52 @@ constexpr double WARM_START_MIN_COMPONENT = 1e-7;
 // One interface over the two solvers: the MFMA squaring solver with its carried state for p <= 16, the row-distributed
 // power iteration above it.
 template <int P, bool MFMA = (P <= 16)> struct Solver;
+#ifndef DN_SOLVER_DPP
+#define DN_SOLVER_DPP 1          // 1: top_eig_dpp (round 4), 0: top_eig_mfma (rounds 1-3)
+#endif
 template <int P> struct Solver<P, true> {
+#if DN_SOLVER_DPP
+    EigStateD<P> st;
+    // component i of the iterate sits in lane i (of every 16-lane row)
+    __device__ __forceinline__ double iterate_of_row() const { return st.vl; }
+    static __device__ __forceinline__ int row_of_lane() { return lane_id() & 15; }
+    static __device__ __forceinline__ double bcast_component(double t, int i) { return bcast_lane<P>(t, i); }
+#else
     EigState<P> st;
+#endif
     __device__ __forceinline__ void cold(double tr, double (&u)[P]) { (void) u; eig_state_cold<P>(st, tr); }
     // the next solve starts from the normalised indicator vector of the rows in `rows` (scale and shift stay): solve_by_blocks
     __device__ __forceinline__ void start_from(unsigned long long rows, double (&u)[P])
     {
         (void) u;
-        const int q = lane_id() >> 4;
         const double u0 = 1.0 / sqrt((double) __builtin_popcountll(rows));
+#if DN_SOLVER_DPP
+        st.vl = ((rows >> (lane_id() & 15)) & 1ull) ? u0 : 0.0;
+        st.k0 = 0; st.rho2 = 1.0; st.age = 0;                // nothing is known about this start: look after every step
+#else
+        const int q = lane_id() >> 4;
 #pragma unroll
         for (int kb = 0; kb < EigState<P>::KB; kb++) st.v[kb] = ((rows >> (q + 4 * kb)) & 1ull) ? u0 : 0.0;
+#endif
     }
     // the shift of the carried state is taken from the top block's eigenvalue: mu < theta / 2 keeps the TOP of the matrix on top,
     // but inside another block it can put the bottom of that block's spectrum on top -- block-by-block solves run unshifted
-    __device__ __forceinline__ void no_shift() { st.mu = 0.0; }
+    __device__ __forceinline__ void no_shift()
+    {
+        st.mu = 0.0;
+    }
     __device__ __forceinline__ double shift() const { return st.mu; }
     static constexpr bool SHIFTED = true;
-    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs)
-    { return top_eig_mfma<P>(tot, zslot, u, theta, st, exact, maxs); }
+    // cold: the first solve of an nmf() call (it may set what the call's warm solves keep: shift, scale)
+    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs, bool cold = false)
+    {
+#if DN_SOLVER_DPP
+        return top_eig_dpp<P>(tot, zslot, u, theta, st, exact, cold, maxs);
+#else
+        (void) cold;
+        return top_eig_mfma<P>(tot, zslot, u, theta, st, exact, maxs);
+#endif
+    }
 };
 template <int P> struct Solver<P, false> {
     __device__ __forceinline__ void cold(double tr, double (&u)[P])
@@ -750,8 +933,8 @@ template <int P> struct Solver<P, false> {
     __device__ __forceinline__ void no_shift() {}                     // top_eig_rows derives its shift from the start vector's own quotient
     __device__ __forceinline__ double shift() const { return 0.0; }
     static constexpr bool SHIFTED = false;
-    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs)
-    { (void) zslot; (void) exact; return top_eig_rows<P>(tot, u, theta, maxs); }
+    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs, bool cold = false)
+    { (void) zslot; (void) exact; (void) cold; return top_eig_rows<P>(tot, u, theta, maxs); }
 };
 
 // The block-by-block solve of the safe path.  Rows i, j of the Gram matrix are linked when G_ij > 0 (sums of non-negative
@@ -819,13 +1002,6 @@ __device__ __forceinline__ int solve_by_blocks(Solver<P> &solver, const double *
     for (int i = 0; i < P; i++) u[i] = bu[i];
     theta = bth > 0.0 ? bth : 0.0;
     return capped ? maxs + 1 : (steps < maxs ? steps : maxs);
-}
-
-// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
-template <int I, int I1, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < I1) { f(std::integral_constant<int, I>{}); static_for<I + 1, I1>(f); }
 }
 
 typedef double gram_t;         // per-lane Gram accumulators
@@ -1558,7 +1734,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     }
     {
         const int r = SAFE ? solve_by_blocks<P>(solver, sm.tot, Smem<P, NT>::ZSLOT, u, theta, maxs)
-                           : solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, T == 0, maxs);
+                           : solver.run(sm.tot, Smem<P, NT>::ZSLOT, u, theta, T == 0, maxs, true);
         steps += r; noconv = noconv || r > maxs;
     }
     const double c = 1.0 / sqrt((double) T);                         // nmf.py:91
@@ -1566,6 +1742,12 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     // iterate layout (lane group q holds v[q + 4 kb]) and broadcast from there
     auto pass_u = [&]() {
         if constexpr (RAW) {
+#if DN_SOLVER_DPP
+            const int k = Solver<P>::row_of_lane() < P ? Solver<P>::row_of_lane() : P - 1;
+            const double vt = solver.iterate_of_row() * g_gs.inv[k], vh = solver.iterate_of_row() * g_gs.scl[k];
+#pragma unroll
+            for (int i = 0; i < P; i++) { ud[i] = Solver<P>::bcast_component(vt, i); ur[i] = Solver<P>::bcast_component(vh, i); }
+#else
             constexpr int KB = EigState<P>::KB;
             const int q = lane_id() >> 4;
             double vt[KB], vh[KB];
@@ -1583,6 +1765,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
                 ur[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b_), 16 * (i & 3)),
                                          __builtin_amdgcn_readlane(__double2loint(b_), 16 * (i & 3)));
             }
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < P; i++) { u[i] = uniform(u[i]); ud[i] = u[i]; ur[i] = u[i]; }
@@ -1798,9 +1981,13 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     if constexpr (RAW) {
 #pragma unroll
         for (int i = 0; i < P; i++) {
+#if DN_SOLVER_DPP
+            u[i] = Solver<P>::bcast_component(solver.iterate_of_row(), i);
+#else
             const double t_ = solver.st.v[i >> 2];
             u[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t_), 16 * (i & 3)),
                                     __builtin_amdgcn_readlane(__double2loint(t_), 16 * (i & 3)));
+#endif
         }
     }
     }   // narrow cohorts

@@ -89,6 +89,66 @@ def synth_gene(seed, g, p, l_min=200, l_max=5000, dtype=np.float64):
     return cov, cls
 
 
+def pileup_gene(seed, g, p, l_min=300, l_max=3000, dtype=np.float64):
+    """
+    Read pile-up coverage of gene g: what DegNorm's real input looks like (reads.py:714,773 -- every base of a read adds 1 to the
+    coverage of the positions it spans), as opposed to synth_gene's envelope x Poisson draw: reads of 75-150 bases stacked at low to
+    medium depth, so the coverage is a piecewise-constant small integer; per sample a 3' bias (start density rising towards the 3'
+    end by a random exponent: degradation), optionally uneven exon depth and a stretch without reads.  Genes of this kind have
+    exact ties everywhere (10 x == max on integer counts, equal bin means): the kind the round-3 fuzz run called `steps`.
+
+    :return: (coverage (p x L) ndarray of whole numbers, kind id: 0 plain, 1 3' decay, 2 decay + uneven exons, 3 decay + a gap)
+    """
+    rng = np.random.default_rng([int(seed), int(g), 77])
+    L = int(rng.integers(l_min, l_max + 1))
+    kind = int(rng.integers(0, 4))
+    depth = float(rng.choice([2., 5., 12., 30.]))                 # mean coverage of the best-covered sample
+    abund = rng.lognormal(0., 0.5, size=p)
+    abund /= abund.max()
+    pos = (np.arange(L) + 0.5) / L
+    exon = np.ones(L)
+    if kind == 2:                                                  # uneven exon usage: piecewise-constant multipliers
+        cuts = np.sort(rng.integers(1, L, size=int(rng.integers(1, 5))))
+        lv = rng.uniform(0.3, 1.0, size=len(cuts) + 1)
+        exon = lv[np.searchsorted(cuts, np.arange(L), side='right')]
+    cov = np.zeros((p, L))
+    for i in range(p):
+        dens = exon.copy()
+        if kind >= 1 and rng.random() < 0.7:
+            dens = dens * (0.05 + pos) ** rng.uniform(0.3, 2.5)   # 3' bias of a degraded sample
+        if kind == 3:
+            a = int(rng.integers(0, L)); b = min(L, a + int(rng.integers(20, max(21, L // 4))))
+            dens[a:b] = 0.
+        if not dens.any():
+            dens[:] = 1.
+        cdf = np.cumsum(dens); cdf /= cdf[-1]
+        n_reads = int(rng.poisson(depth * abund[i] * L / 112.))
+        mid = np.searchsorted(cdf, rng.random(n_reads))            # read midpoints follow the density
+        rl = rng.integers(75, 151, size=n_reads)
+        lo = np.clip(mid - rl // 2, 0, L)
+        hi = np.clip(lo + rl, 0, L)
+        d = np.zeros(L + 1)
+        np.add.at(d, lo, 1.); np.add.at(d, hi, -1.)
+        cov[i] = np.cumsum(d[:L])
+    if not cov.any():
+        cov[0, :min(L, 100)] = 1.
+    return cov.astype(dtype), kind
+
+
+def pileup_dataset(seed, gene_ids, p, l_min=300, l_max=3000, dtype=np.float64):
+    """pile-up genes in the shape synth_dataset returns; read counts = reads whose midpoint falls in the gene ~ rowsum / 112"""
+    cov_dat = OrderedDict()
+    gene_ids = list(gene_ids)
+    reads = np.zeros((len(gene_ids), p))
+    kinds = np.zeros(len(gene_ids), dtype=np.int32)
+    for k, g in enumerate(gene_ids):
+        cov, kind = pileup_gene(seed, g, p, l_min, l_max, dtype=dtype)
+        cov_dat['pileup_{0:06d}'.format(g)] = cov
+        reads[k] = np.round(cov.sum(axis=1, dtype=np.float64) / 112.)
+        kinds[k] = kind
+    return cov_dat, reads, kinds
+
+
 def read_counts_from_coverage(cov):
     """Read counts of a gene: round(rowsum / 100)."""
     return np.round(cov.sum(axis=1, dtype=np.float64) / 100.)

@@ -20,6 +20,8 @@ Sections:
     warm       G7     warm-start directory -> filter -> run -> save_results CSVs
     merge      f-3    merge_chrom_coverage on per-sample chromosome CSR vectors
     sparse     G3b    baseline_selection on sparse genes: decoupled sample blocks, samples losing all coverage (three stable runs each)
+    pileup     G3c    baseline_selection on read pile-up coverage (piecewise-constant small integers: DegNorm's real input kind), three runs
+                      each, + GeneNMFOA.run on 48 such genes for 3 iterations
 """
 import os
 import sys
@@ -377,6 +379,79 @@ def sec_sparse():
     print('sparse: kept %d of %d tried (%d with decoupled samples) in %.0f s' % (len(keep), tried, sum(g['decoupled'] for g in keep), time.time() - t0))
 
 
+def sec_pileup():
+    """
+    Read pile-up coverage (synth.pileup_gene: reads of 75-150 bases stacked at low / medium depth with 3' bias -> piecewise-constant
+    small integers, what reads.py:714,773 really produces) through the reference.  Such genes are full of exact ties (10 x == max in
+    get_high_coverage_idx, equal bin means in the drop loop, exact-zero residuals), i.e. the inputs on which summation order can
+    decide a branch.  Every gene is run THREE times through baseline_selection (ARPACK's start vector is random) and kept when call
+    sequence, flag, rho (1e-9) and estimate row sums agree; the number of unstable genes is recorded too -- that is the reference's
+    own noise floor on this input kind.  p in {4, 6, 10}, T in {20, 100}; then one GeneNMFOA.run (p = 6, 48 genes, 3 iterations).
+    """
+    rng = np.random.default_rng(4242)
+    keep, unstable, tried = [], 0, 0
+    t0 = time.time()
+    g = 0
+    while len(keep) < 120 and tried < 400:
+        tried += 1
+        p = int(rng.choice([4, 6, 10]))
+        T = int(rng.choice([20, 100]))
+        x, kind = synth.pileup_gene(11, g, p, 300, 2200)
+        g += 1
+        scale = np.exp(rng.uniform(-0.4, 0.4, p)) if rng.random() < 0.7 else np.ones(p)
+        F = (x.T / scale).T
+        runs = []
+        for rep in range(3):
+            m = GeneNMFOA(degnorm_iter=1, nmf_iter=T, n_jobs=1)
+            m.p = p
+            calls = []
+            inner = m.nmf
+
+            def nmf(xx, factors=False, inner=inner, calls=calls):
+                out = inner(xx, factors=factors)
+                calls.append(xx.shape[1])
+                return out
+            m.nmf = nmf
+            try:
+                r, est, fl = m.baseline_selection(F.copy())
+            except Exception:
+                runs = None
+                break
+            runs.append((np.asarray(r, dtype=float).ravel(), bool(fl), list(calls), est.sum(axis=1)))
+        if not runs:
+            continue
+        stable = all(rr[1] == runs[0][1] and rr[2] == runs[0][2] and np.allclose(rr[0], runs[0][0], rtol=1e-9, atol=1e-11)
+                     and np.allclose(rr[3], runs[0][3], rtol=1e-8, atol=1e-8) for rr in runs[1:])
+        if not stable:
+            unstable += 1
+            continue
+        keep.append(dict(gene=g - 1, p=p, T=T, kind=kind, scale=scale, rho=runs[0][0], flag=runs[0][1], calls=runs[0][2],
+                         est_rowsum=runs[0][3], ck=checksum(x)))
+    out = dict(n=len(keep), seed=11, l_min=300, l_max=2200, tried=tried, unstable=unstable)
+    for k, q in enumerate(keep):
+        out['scale%d' % k] = q['scale']; out['rho%d' % k] = q['rho']; out['est_rowsum%d' % k] = q['est_rowsum']
+        out['calls%d' % k] = np.array(q['calls'], dtype=np.int32)
+        out['prm%d' % k] = np.array([q['gene'], q['p'], q['T'], q['kind'], int(q['flag'])], dtype=np.int64)
+        out['ck%d' % k] = q['ck']
+    print('pileup genes: kept %d of %d tried, %d unstable in the reference itself, %.0f s' % (len(keep), tried, unstable, time.time() - t0))
+    # whole chain on the same input kind: 48 genes, p = 6, 3 outer iterations (scale factors, DI, flags, traces per iteration)
+    gene_ids = list(range(1000, 1048))
+    cov_dat, reads, kinds = synth.pileup_dataset(12, gene_ids, 6, 300, 2500)
+    m = GeneNMFOA(degnorm_iter=3, nmf_iter=100, n_jobs=1)
+    tr = Tracer(m)
+    t1 = time.time()
+    est = m.run(cov_dat, reads)
+    n = len(gene_ids)
+    n_calls, sum_cols, n0 = trace_arrays(tr.calls)
+    out.update(run_seed=12, run_p=6, run_l_min=300, run_l_max=2500, run_gene_ids=np.array(gene_ids), run_reads=reads, run_kinds=kinds,
+               run_checksum=np.array([checksum(c) for c in cov_dat.values()]), run_rho=m.rho, run_x_adj=m.x_adj,
+               run_flags=m.ran_baseline_selection, run_scale_factors=m.scale_factors, run_rho_hist=np.stack(tr.rho_hist),
+               run_scale_hist=np.stack(tr.scale_hist), run_n_calls=n_calls.reshape(3, n), run_sum_cols=sum_cols.reshape(3, n),
+               run_n0=n0.reshape(3, n), run_est_rowsum=np.vstack([e.sum(axis=1) for e in est]))
+    np.savez_compressed(os.path.join(HERE, 'pileup.npz'), **out)
+    print('pileup run: %d genes x 3 iterations in %.0f s' % (n, time.time() - t1))
+
+
 
 def sec_mpi():
     seed, p, l_min, l_max, n = 7, 4, 200, 1200, 30
@@ -476,7 +551,7 @@ def sec_merge():
 
 
 SECTIONS = OrderedDict(kat=sec_kat, genes=sec_genes, run_c1=sec_run_c1, run_c2=sec_run_c2, run_c2_deep=sec_run_c2_deep, mpi=sec_mpi,
-                       dsamp=sec_dsamp, warm=sec_warm, merge=sec_merge, sparse=sec_sparse)
+                       dsamp=sec_dsamp, warm=sec_warm, merge=sec_merge, sparse=sec_sparse, pileup=sec_pileup)
 
 if __name__ == '__main__':
     import logging

@@ -171,3 +171,57 @@ def test_sparse_genes_vs_reference_golden(oracle):
         np.testing.assert_allclose(est[0].sum(axis=1), c['est_rowsum'], rtol=1e-8, atol=1e-8, err_msg=msg)
         n += 1; n_dec += c['decoupled']; n_zero += int(trace[0, 4] == 3)
     assert n >= 60 and n_dec >= 20 and n_zero >= 3          # the fixture holds what it was made for
+
+
+def pileup_golden_cases():
+    """tests/golden/pileup.npz (make_golden.py pileup): read pile-up genes with the reference's outputs (three agreeing runs each)."""
+    from degnorm_amd import synth
+    G = golden('pileup')
+    for k in range(int(G['n'])):
+        gene, p, T, kind, flag = [int(v) for v in G['prm%d' % k]]
+        x, kind_g = synth.pileup_gene(int(G['seed']), gene, p, int(G['l_min']), int(G['l_max']))
+        assert kind_g == kind and input_checksum(x) == float(G['ck%d' % k])              # the generator has not drifted
+        yield dict(k=k, x=x, p=p, T=T, kind=kind, flag=bool(flag), scale=G['scale%d' % k], rho=G['rho%d' % k], calls=G['calls%d' % k],
+                   est_rowsum=G['est_rowsum%d' % k])
+
+
+def pileup_run_inputs(G):
+    from degnorm_amd import synth
+    cov_dat, reads, kinds = synth.pileup_dataset(int(G['run_seed']), G['run_gene_ids'], int(G['run_p']), int(G['run_l_min']), int(G['run_l_max']))
+    covs = list(cov_dat.values())
+    np.testing.assert_array_equal([input_checksum(c) for c in covs], G['run_checksum'])
+    np.testing.assert_array_equal(reads, G['run_reads'])
+    return covs, reads
+
+
+def test_pileup_genes_vs_reference_golden(oracle):
+    """
+    G3c (round 4): the input kind DegNorm really sees -- reads stacked into piecewise-constant small-integer coverage
+    (reads.py:714,773) -- where 10 x == max ties and equal bin means are everywhere.  120 genes (p = 4 / 6 / 10, T = 20 / 100),
+    each run three times through the reference's baseline_selection (all 120 stable): call sequence, flag, DI, estimate row sums.
+    """
+    n = n_loop = 0
+    for c in pileup_golden_cases():
+        rho, flags, trace, est = oracle.baseline_batch([c['x']], c['scale'], oracle.make_params(nmf_iter=c['T']), want_estimates=True)
+        msg = 'pileup golden gene %d (kind %d, p = %d, T = %d)' % (c['k'], c['kind'], c['p'], c['T'])
+        assert trace[0, 1] == len(c['calls']) and trace[0, 2] == c['calls'].sum(), msg
+        assert bool(flags[0]) == c['flag'], msg
+        np.testing.assert_allclose(rho[0], c['rho'], rtol=1e-8, atol=1e-10, err_msg=msg)
+        np.testing.assert_allclose(est[0].sum(axis=1), c['est_rowsum'], rtol=1e-8, atol=1e-8, err_msg=msg)
+        n += 1; n_loop += int(c['flag'])
+    assert n >= 100 and n_loop >= 40
+
+
+def test_pileup_run_vs_reference_golden(oracle):
+    """The whole chain on pile-up coverage: GeneNMFOA.run on 48 genes (p = 6), 3 outer iterations, against the reference's run."""
+    G = golden('pileup')
+    covs, reads = pileup_run_inputs(G)
+    hist = {}
+    out = oracle.run(covs, reads, degnorm_iter=3, nmf_iter=100, history=hist)
+    for i in range(3):
+        np.testing.assert_array_equal(hist['trace'][i][:, 1], G['run_n_calls'][i])
+        np.testing.assert_array_equal(hist['trace'][i][:, 2], G['run_sum_cols'][i])
+    np.testing.assert_array_equal(out['ran_baseline_selection'], G['run_flags'])
+    np.testing.assert_allclose(out['rho'], G['run_rho'], rtol=RT, atol=1e-12)
+    np.testing.assert_allclose(out['x_adj'], G['run_x_adj'], rtol=RT)
+    np.testing.assert_allclose(out['scale_factors'], G['run_scale_factors'], rtol=RT)
