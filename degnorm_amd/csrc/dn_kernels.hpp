@@ -140,6 +140,16 @@ struct Smem {
     double xw[W][NX];                        // per-wave totals (cross-wave combine)
     double tot[NX];                          // block totals (broadcast)
     double dsel[NX];                         // 1.0 at the packed indices of the Gram diagonal, else 0.0
+    // round 4 (top_eig_dpp): the block total of the Gram matrix once more as a SQUARE matrix, rows contiguous and 16-byte aligned,
+    // already multiplied by the solver's scale: lane r of the solver reads its row with 128-bit loads from ONE address (the packed
+    // triangle needs a gather of p addresses held in p registers through the whole T loop).  Rows >= p stay zero.
+    // Every WAVE builds its own copy from the per-wave totals (one barrier per reduction instead of two: nobody waits for a
+    // combining wave), which is why xw is double-buffered for these reductions (xw2: the T loop alternates between the two).
+    static constexpr int SQ_STR = P + (P & 1);
+    static constexpr int SQ_LEN = 16 * SQ_STR;
+    alignas(16) double sq[P <= 16 ? W * SQ_LEN : 2];
+    double xw2[(P <= 16 && W > 1) ? W : 1][(P <= 16 && W > 1) ? NX : 1];
+    int32_t sqi[P <= 16 ? NX : 2];           // packed entry e = (a, b): (a SQ_STR + b) | (b SQ_STR + a) << 16
     double stage[P >= DN_MG_MIN_P ? W * 16 * MG_STR : 2];      // per wave: 16 updated columns in the MFMA operand layout
     double eigv[P >= DN_MG_MIN_P ? W * 2 * 64 : 2];            // per wave: current eigenvector u and a work vector
     double ss[MAX_BINS];                     // per-bin mean squared residual
@@ -211,9 +221,16 @@ __device__ __forceinline__ double shift_total(double s, double d, double diag_sh
     else return fma(-diag_shift, d, s);
 }
 
-template <int N, int OFF, typename VT, bool RAWSC = false>
+// the square, scaled copy of a shifted block total for top_eig_dpp (Smem::sq): both triangles
+__device__ __forceinline__ void sq_store(double *sq, int packed_idx, double t)
+{
+    sq[packed_idx & 0xffff] = t;
+    sq[packed_idx >> 16] = t;
+}
+
+template <int N, int OFF, typename VT, bool RAWSC = false, bool SQ = false>
 __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, int lane, double diag_shift, const double *dsel,
-                                                 bool shift_here)
+                                                 bool shift_here, double *sq = nullptr, const int32_t *sqi = nullptr, double sq_scale = 1.0)
 {
     constexpr int CNT = (N - OFF) < 64 ? (N - OFF) : 64;
     VT part[CNT];
@@ -224,20 +241,42 @@ __device__ __forceinline__ void wave_round_store(const VT (&g)[N], double *dst, 
     if (e < CNT) {
         if (shift_here) s = shift_total<RAWSC>(s, dsel[OFF + e], diag_shift);
         dst[OFF + e] = s;
+        if constexpr (SQ) { if (shift_here) sq_store(sq, sqi[OFF + e], s * sq_scale); }
     }
-    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT, RAWSC>(g, dst, lane, diag_shift, dsel, shift_here);
+    if constexpr (OFF + 64 < N) wave_round_store<N, OFF + 64, VT, RAWSC, SQ>(g, dst, lane, diag_shift, dsel, shift_here, sq, sqi, sq_scale);
 }
 
-template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0, bool RAWSC = false>    // OFF: the totals go to tot[OFF .. OFF + N)
-__device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm, double diag_shift = 0.0)
+template <int N, int P, int NT, typename VT, bool SHIFT = false, int OFF = 0, bool RAWSC = false, bool SQ = false>    // OFF: the totals go to tot[OFF .. OFF + N)
+__device__ __forceinline__ void block_sum_lds(const VT (&g)[N], Smem<P, NT> &sm, double diag_shift = 0.0, double sq_scale = 1.0, int parity = 0)
 {
     static_assert(!RAWSC || SHIFT, "the raw-unit scale rides on the shift step");
+    static_assert(!SQ || (SHIFT && P <= 16), "the square copy is the eigen-solver's view of the shifted Gram matrix");
     static_assert(OFF + N <= Smem<P, NT>::NX - 1, "xw too small");
     static_assert(!SHIFT || OFF + N <= P * (P + 1) / 2, "the shift is for the packed Gram matrix");
     constexpr int W = NT / 64;
     const int lane = lane_id(), w = wave_id();
+    if constexpr (SQ && W > 1) {
+        // The eigen-solver's input only (T loop): per-wave totals into the xw buffer of this call's parity, ONE barrier, then every
+        // wave adds the W totals of each entry itself (same order in every wave: same bits) and writes its own square, scaled copy.
+        // The next reduction writes the other buffer, so a wave still reading here is never overtaken; sm.tot is not written.
+        constexpr int NXW = Smem<P, NT>::NX;
+        double *xwb = parity ? &sm.xw2[0][0] : &sm.xw[0][0];
+        wave_round_store<N, 0, VT, RAWSC, false>(g, xwb + w * NXW + OFF, lane, diag_shift, sm.dsel + OFF, false);
+        DN_MARK("wave_reduced");
+        __syncthreads();
+        double *sqw = sm.sq + w * Smem<P, NT>::SQ_LEN;
+        for (int e = OFF + lane; e < OFF + N; e += 64) {            // one trip unless N > 64
+            double t = xwb[e];
+#pragma unroll
+            for (int ww = 1; ww < W; ww++) t += xwb[ww * NXW + e];
+            t = shift_total<RAWSC>(t, sm.dsel[e], diag_shift);
+            sq_store(sqw, sm.sqi[e], t * sq_scale);
+        }
+        wave_fence();
+        return;
+    }
     double *dst = ((W > 1) ? sm.xw[w] : sm.tot) + OFF;
-    wave_round_store<N, 0, VT, RAWSC>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1);     // ceil(N / 64) rounds
+    wave_round_store<N, 0, VT, RAWSC, SQ>(g, dst, lane, diag_shift, sm.dsel + OFF, SHIFT && W == 1, sm.sq, sm.sqi + OFF, sq_scale);     // ceil(N / 64) rounds
     DN_MARK("wave_reduced");
     if constexpr (W > 1) {
         __syncthreads();
@@ -578,6 +617,7 @@ struct EigStateD {
     double sc;           // ~ 1 / (theta - mu): un-normalised steps keep the iterate's length
     double mu;           // shift in the units of G (0: none); the caller subtracts it from the diagonal in LDS
     double rho2;         // contraction of d2 per step, as last measured (1: not yet)
+    double q;            // min(1, 4 rho2): a look has converged when d2 q <= 1e-26
     int k0;              // blind steps of the next solve
     int age;             // solves since rho2 was measured
 };
@@ -589,6 +629,7 @@ __device__ __forceinline__ void eig_state_cold(EigStateD<P> &st, double tr)
     st.sc = __builtin_amdgcn_rcp(tr);
     st.mu = 0.0;
     st.rho2 = 1.0;
+    st.q = 1.0;
     st.k0 = 0;
     st.age = 0;
 }
@@ -608,9 +649,10 @@ constexpr int EIG_RHO_MAX_AGE = 8;
 // theta the eigenvalue of G -- the exact Rayleigh quotient when asked for (the last solve of a call), an estimate after a cold
 // solve (it sets shift and scale), untouched otherwise.  COLD: the first solve of an nmf() call.
 // ss (diagnostics, tools/ubench/solver_ab.hip): cycles per phase { load, blind steps, first normalisation, looks, epilogue }
-template <int P, bool STAMP = false>
+template <int P, bool STAMP = false, bool SQUARE = false>
 __device__ __forceinline__ int top_eig_dpp(const double *tot, int zslot, double (&u)[P], double &theta, EigStateD<P> &st,
-                                           bool exact_theta, bool cold, int maxs = EIG_MAX_STEPS_DEFAULT, long long *ss = nullptr)
+                                           bool exact_theta, bool cold, int maxs = EIG_MAX_STEPS_DEFAULT, long long *ss = nullptr,
+                                           const double *sq = nullptr)
 {
     static_assert(P <= 16, "one row of the matrix per lane of a 16-lane DPP row");
     long long t_last = 0;
@@ -626,10 +668,19 @@ __device__ __forceinline__ int top_eig_dpp(const double *tot, int zslot, double 
     const int r = lane_id() & 15;
     const double sc = st.sc, mu = st.mu;
     double Hr[P];
+    if constexpr (SQUARE) {
+        // the caller's reduction left (G - mu I) sc as a square matrix (Smem::sq): this lane's row in 128-bit loads from one address
+        constexpr int STR = P + (P & 1);
+        const double *row = sq + r * STR;
 #pragma unroll
-    for (int j = 0; j < P; j++) {
-        const int a = r > j ? r : j, b = r > j ? j : r;
-        Hr[j] = tot[r < P ? a * (a + 1) / 2 + b : zslot] * sc;            // rows >= P are zero and stay zero
+        for (int j = 0; j + 1 < P; j += 2) { const double2 h2 = *reinterpret_cast<const double2 *>(row + j); Hr[j] = h2.x; Hr[j + 1] = h2.y; }
+        if constexpr (P & 1) Hr[P - 1] = row[P - 1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const int a = r > j ? r : j, b = r > j ? j : r;
+            Hr[j] = tot[r < P ? a * (a + 1) / 2 + b : zslot] * sc;        // rows >= P are zero and stay zero
+        }
     }
     DN_MARK("solver_loaded");
     double v = st.vl;
@@ -639,36 +690,47 @@ __device__ __forceinline__ int top_eig_dpp(const double *tot, int zslot, double 
     const int kb = k0 - (probe ? 1 : 0);
     int steps = kb;
     stamp(0);
+    // the length stays ~1: sc ~ 1 / (theta - mu).  Two steps per trip: a taken branch costs a wave alone on its SIMD ~10 issue slots
+    if (kb & 1) v = dpp_matvec<P>(Hr, v);
 #pragma clang loop unroll(disable)
-    for (int k = 0; k < kb; k++) v = dpp_matvec<P>(Hr, v);                // the length stays ~1: sc ~ 1 / (theta - mu)
+    for (int k = kb >> 1; k > 0; k--) v = dpp_matvec<P>(Hr, dpp_matvec<P>(Hr, v));
     stamp(1);
-    double n2 = dpp_rowdot<P>(v, v);
-    if (!wave_any(n2 > 0.0)) { theta = 0.0; return steps + 1; }
-    double ua = v * rsqrt_newton(n2);
+    // (a zero matrix -- a sample block without coverage in solve_by_blocks -- gives NaN from here on: no look converges on NaN, and
+    // the slow path below sorts it out; the common path carries no test for it)
+    double ua = v * rsqrt_newton(dpp_rowdot<P>(v, v));
     double rho2 = st.rho2;
-    double d2_prev = 0.0, d2 = 0.0, ylen = 1.0;
-    int extra = 0;                                                         // looks beyond the first
-    bool conv = false;
-    stamp(2);
-    for (;;) {
+    double d2 = 0.0, ylen = 1.0, m2 = 1.0;
+    // one look: a step from the unit vector u_a, the new unit vector, the squared distance between the two
+    auto look = [&]() {
         const double y = dpp_matvec<P>(Hr, ua);
         steps++;
-        n2 = dpp_rowdot<P>(y, y);
-        if (!wave_any(n2 > 0.0)) { theta = 0.0; return steps; }
-        const double inv = rsqrt_newton(n2);
-        ylen = n2 * inv;                                                   // |H u_a| ~ (theta - mu) sc
+        m2 = dpp_rowdot<P>(y, y);
+        const double inv = rsqrt_newton(m2);
+        ylen = m2 * inv;                                                   // |H u_a| ~ (theta - mu) sc
         const double ub = y * inv;
         const double d = ub - ua;
         d2 = dpp_rowdot<P>(d, d);
         ua = ub;
-        if (extra > 0) {                                                   // a second look: the contraction, measured (the floor keeps a
-            const double m = d2 * __builtin_amdgcn_rcp(d2_prev);           // difference of round-off from passing for fast convergence)
-            rho2 = m > 1e-8 ? m : 1e-8;
+    };
+    stamp(2);
+    look();
+    // the common case is over here: converged by the carried contraction (no short-circuit logic: one compare, one scalar branch)
+    double q = st.q;
+    bool conv = wave_any(d2 * q <= 1e-26);
+    int extra = 0;                                                         // looks beyond the first
+    if (!conv || probe) {
+        if (!wave_any(m2 > 0.0)) { theta = 0.0; return steps; }           // H v = 0: nothing to find (theta = 0 tells the caller)
+        while (steps < maxs) {
+            const double d2_prev = d2;
+            extra++;
+            look();
+            if (!wave_any(m2 > 0.0)) { theta = 0.0; return steps; }
+            const double m = d2 * __builtin_amdgcn_rcp(d2_prev);           // the contraction, measured; the floor keeps a difference
+            rho2 = m > 1e-8 ? m : 1e-8;                                    // of round-off from passing for fast convergence
+            q = 4.0 * rho2 < 1.0 ? 4.0 * rho2 : 1.0;
+            conv = wave_any(d2 * q <= 1e-26);
+            if (conv) break;
         }
-        conv = wave_any((d2 <= 1e-26) | (4.0 * d2 * rho2 <= 1e-26)) && !(probe && extra == 0);
-        if (conv || steps >= maxs) break;
-        d2_prev = d2;
-        extra++;
     }
     stamp(3);
     DN_MARK("solver_checked");
@@ -686,6 +748,7 @@ __device__ __forceinline__ int top_eig_dpp(const double *tot, int zslot, double 
     }
     st.vl = ua;
     st.rho2 = rho2;
+    st.q = q;
     st.age = extra > 0 ? 0 : age + 1;
     // the next solve takes one blind step less when this one converged with a whole step to spare (4 d2_(k-1) rho^2 = 4 d2 <= 1e-26,
     // with a margin of 4), and as many more as this one needed looks beyond its first
@@ -890,7 +953,7 @@ template <int P> struct Solver<P, true> {
         const double u0 = 1.0 / sqrt((double) __builtin_popcountll(rows));
 #if DN_SOLVER_DPP
         st.vl = ((rows >> (lane_id() & 15)) & 1ull) ? u0 : 0.0;
-        st.k0 = 0; st.rho2 = 1.0; st.age = 0;                // nothing is known about this start: look after every step
+        st.k0 = 0; st.rho2 = 1.0; st.q = 1.0; st.age = 0;    // nothing is known about this start: look after every step
 #else
         const int q = lane_id() >> 4;
 #pragma unroll
@@ -904,14 +967,19 @@ template <int P> struct Solver<P, true> {
         st.mu = 0.0;
     }
     __device__ __forceinline__ double shift() const { return st.mu; }
+    __device__ __forceinline__ double scale() const { return st.sc; }
     static constexpr bool SHIFTED = true;
+    static constexpr bool SQUARE = DN_SOLVER_DPP != 0;                  // takes the scaled square copy of the matrix
     // cold: the first solve of an nmf() call (it may set what the call's warm solves keep: shift, scale)
-    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs, bool cold = false)
+    // sq: the matrix once more as the scaled square copy a block_sum_lds<..., SQ> left (Smem::sq), or null
+    template <bool SQ = false>
+    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs, bool cold = false,
+                                       const double *sq = nullptr)
     {
 #if DN_SOLVER_DPP
-        return top_eig_dpp<P>(tot, zslot, u, theta, st, exact, cold, maxs);
+        return top_eig_dpp<P, false, SQ>(tot, zslot, u, theta, st, exact, cold, maxs, nullptr, sq);
 #else
-        (void) cold;
+        (void) cold; (void) sq;
         return top_eig_mfma<P>(tot, zslot, u, theta, st, exact, maxs);
 #endif
     }
@@ -932,9 +1000,13 @@ template <int P> struct Solver<P, false> {
     }
     __device__ __forceinline__ void no_shift() {}                     // top_eig_rows derives its shift from the start vector's own quotient
     __device__ __forceinline__ double shift() const { return 0.0; }
+    __device__ __forceinline__ double scale() const { return 1.0; }
     static constexpr bool SHIFTED = false;
-    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs, bool cold = false)
-    { (void) zslot; (void) exact; (void) cold; return top_eig_rows<P>(tot, u, theta, maxs); }
+    static constexpr bool SQUARE = false;
+    template <bool SQ = false>
+    __device__ __forceinline__ int run(const double *tot, int zslot, double (&u)[P], double &theta, bool exact, int maxs, bool cold = false,
+                                       const double *sq = nullptr)
+    { (void) zslot; (void) exact; (void) cold; (void) sq; return top_eig_rows<P>(tot, u, theta, maxs); }
 };
 
 // The block-by-block solve of the safe path.  Rows i, j of the Gram matrix are linked when G_ij > 0 (sums of non-negative
@@ -1796,6 +1868,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
     stamp[3] += __builtin_amdgcn_s_memtime() - t_cold0;
 #endif
     constexpr bool G0 = FULL && ONCHIP && SW == 1;          // the first tier column STARTS the Gram accumulators (no zeroing)
+    constexpr bool SQ = Solver<P>::SQUARE && SW == 1 && !SAFE;   // the solver reads the scaled square copy of the Gram matrix (Smem::sq)
 #pragma clang loop unroll(disable)
     for (int t = 0; t < T; t++) {
         DN_MARK("iter_begin");
@@ -1939,7 +2012,7 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         DN_T1(0);
 #endif
         }
-        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED, 0, RAW>(G, sm, solver.shift()); DN_T1(1); }   // tot = G - mu I
+        { DN_T0(); block_sum_lds<CH, P, NT, gram_t, Solver<P>::SHIFTED, 0, RAW, SQ>(G, sm, solver.shift(), solver.scale(), t & 1); DN_T1(1); }   // tot = G - mu I
         DN_MARK("reduced");
         // later sweeps (p >= 16): the remaining Gram entries from the updated state, read-only
         static_for<1, SW>([&](auto qc) {
@@ -1971,13 +2044,15 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
         double u_unused[P];
         double (&us_)[P] = RAW ? u_unused : u;
         const int r = SAFE ? solve_by_blocks<P>(solver, sm.tot, Smem<P, NT>::ZSLOT, us_, theta, maxs)
-                           : solver.run(sm.tot, Smem<P, NT>::ZSLOT, us_, theta, t == T - 1, maxs);   // sigma^2 is only read after the last solve
+                           : solver.template run<SQ>(sm.tot, Smem<P, NT>::ZSLOT, us_, theta, t == T - 1, maxs, false,
+                                                     sm.sq + wave_id() * Smem<P, NT>::SQ_LEN);   // sigma^2 is only read after the last solve
         steps += r; noconv = noconv || r > maxs;
         pass_u();
         DN_MARK("solved");
         DN_T1(2);
         }
     }
+    if constexpr (SQ && NT > 64) dn_sync();                 // the loop's last reduction had one barrier: no wave is still reading xw / xw2
     if constexpr (RAW) {
 #pragma unroll
         for (int i = 0; i < P; i++) {
@@ -2133,7 +2208,8 @@ __global__ __launch_bounds__(NT * DN_UNITS, DN_KERNEL_WAVES) void k_baseline(Ite
     DN_RT_CLAIM();
     if (tid < P) { gs.inv[tid] = A.inv_scale[tid]; gs.scl[tid] = 1.0 / A.inv_scale[tid]; }
     if (tid == 0) gs.max_steps = A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT;
-    for (int t = tid; t < Smem<P, NT>::NX; t += NT) {                  // constants of the eigen-solver (top_eig_mfma)
+    if constexpr (P <= 16) { for (int t = tid; t < W * Smem<P, NT>::SQ_LEN; t += NT) sm.sq[t] = 0.0; }    // rows >= p of the square copies stay zero
+    for (int t = tid; t < Smem<P, NT>::NX; t += NT) {                  // constants of the eigen-solver
         bool diag = false;
         int ra = 0, rb = 0;                                             // packed entry t = (ra, rb), rb <= ra
 #pragma unroll
@@ -2141,6 +2217,7 @@ __global__ __launch_bounds__(NT * DN_UNITS, DN_KERNEL_WAVES) void k_baseline(Ite
             diag = diag || (t == i * (i + 1) / 2 + i);
             if (t >= i * (i + 1) / 2) { ra = i; rb = t - i * (i + 1) / 2; }
         }
+        if constexpr (P <= 16) sm.sqi[t] = (t < P * (P + 1) / 2) ? (ra * Smem<P, NT>::SQ_STR + rb) | ((rb * Smem<P, NT>::SQ_STR + ra) << 16) : 0;
         if constexpr (raw_units<P>())                                   // raw-unit Gram totals: the entry's scale, negative on the diagonal (shift_total)
             sm.dsel[t] = (t < P * (P + 1) / 2) ? (diag ? -1.0 : 1.0) * A.inv_scale[ra] * A.inv_scale[rb < P ? rb : 0] : 0.0;
         else sm.dsel[t] = diag ? 1.0 : 0.0;
