@@ -93,6 +93,15 @@ def load(build_if_missing=False):
                                          P(c.c_float), P(dbl)]
     lib.dn_assemble_last_error.restype = c.c_char_p
     lib.dn_outer_partials_device.argtypes = [vp, P(vp)]
+    lib.dn_comm_unique_id.argtypes = [P(c.c_uint8)]
+    lib.dn_comm_create.argtypes = [vp, P(c.c_uint8), i32, i32]
+    lib.dn_comm_destroy.argtypes = [vp]
+    lib.dn_comm_size.argtypes = [vp]
+    lib.dn_comm_size.restype = i32
+    lib.dn_comm_library.restype = c.c_char_p
+    lib.dn_comm_allreduce.argtypes = [vp, P(dbl), i32]
+    lib.dn_init_allreduce.argtypes = [vp, P(dbl)]
+    lib.dn_outer_allreduce.argtypes = [vp, P(dbl)]
     _lib = lib
     return lib
 
@@ -273,6 +282,50 @@ class Device:
         ptr = ctypes.c_void_p()
         _check(self.lib.dn_outer_partials_device(self.h, ctypes.byref(ptr)))
         return int(ptr.value), 3 * self.p + 4
+
+    # -- the collective inside the library (dn_comm_*: RCCL on the handle's stream) ------------------
+    COMM_ID_BYTES = 128
+
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: the opaque bytes every rank hands to comm_create (ncclGetUniqueId)."""
+        buf = np.zeros(Device.COMM_ID_BYTES, dtype=np.uint8)
+        _check(load().dn_comm_unique_id(_p(buf, ctypes.c_uint8)))
+        return buf
+
+    def comm_create(self, unique_id, rank, size):
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        if uid.shape != (Device.COMM_ID_BYTES,):
+            raise ValueError('the communicator id is {0} bytes'.format(Device.COMM_ID_BYTES))
+        _check(self.lib.dn_comm_create(self.h, _p(uid, ctypes.c_uint8), int(rank), int(size)))
+
+    def comm_destroy(self):
+        _check(self.lib.dn_comm_destroy(self.h))
+
+    def comm_size(self):
+        return int(self.lib.dn_comm_size(self.h))
+
+    @staticmethod
+    def comm_library():
+        return load().dn_comm_library().decode()
+
+    def comm_allreduce(self, vec):
+        """Sum a small float64 vector over the ranks of this handle's communicator."""
+        v = np.array(vec, dtype=np.float64).ravel()
+        _check(self.lib.dn_comm_allreduce(self.h, _p(v, ctypes.c_double), int(v.size)))
+        return v
+
+    def init_allreduce(self):
+        """dn_init_partials of this shard summed over the ranks (3p + 4)."""
+        v = np.zeros(3 * self.p + 4)
+        _check(self.lib.dn_init_allreduce(self.h, _p(v, ctypes.c_double)))
+        return v
+
+    def outer_allreduce(self):
+        """dn_outer_partials of this shard summed over the ranks (3p + 4): no host hop before the collective."""
+        v = np.zeros(3 * self.p + 4)
+        _check(self.lib.dn_outer_allreduce(self.h, _p(v, ctypes.c_double)))
+        return v
 
     def outer_apply(self, avg_di, norm, it):
         norm = np.ascontiguousarray(norm, dtype=np.float64)

@@ -113,7 +113,7 @@ def build_library(force=False, verbose=False):
                 if verbose and out.strip():
                     print(out)
     if force or jobs or _newer(LIB, objs):
-        _run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs)
+        _run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl'])
     return LIB
 
 

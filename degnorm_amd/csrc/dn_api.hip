@@ -3,6 +3,9 @@
 #include "dn_kernels.hpp"
 #include "../../include/degnorm_amd.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and constants only: the entry points are resolved at run time (rccl_api below)
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -371,6 +374,10 @@ struct dn_handle_s {
     float last_init_ms = 0.f;     // device time of the most recent dn_ratio_svd_sums kernel
     char init_name[64] = {0};
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr;
+    // the collective inside the library (dn_comm_*): one RCCL communicator per handle, all-reduces on the handle's stream
+    void *comm = nullptr;         // ncclComm_t
+    int32_t comm_rank = 0, comm_size = 0;
+    double *d_comm = nullptr;     // 256 doubles of scratch (ranks without genes, small host vectors)
     int32_t ds_hint = 1;          // take-every rate the caller intends to use (dn_set_downsample_hint); 1 = none
     int32_t max_steps = dn::EIG_MAX_STEPS_DEFAULT;   // step cap of one eigen-solve (dn_set_solver_step_cap)
     // per-gene counters of the previous dn_baseline_iteration: the narrow class orders its queue by the work they predict
@@ -381,6 +388,53 @@ struct dn_handle_s {
     bool have_trace = false;
 
 };
+
+// ---------------------------------------------------------------------------------------------------
+// RCCL, resolved at run time.  The library carries no link-time dependency on librccl: a host process that already
+// has one mapped (PyTorch ships its own copy) must share THAT copy -- two RCCL instances in one process each bring their
+// own proxy threads and IPC state --, and a host without any multi-GPU use never loads it.  Order: a copy already in
+// the process (RTLD_NOLOAD), DN_RCCL_PATH, the system's librccl.so.1.
+// ---------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    std::string path;
+};
+
+static RcclApi *rccl_api(std::string &err)
+{
+    static RcclApi api;
+    static bool tried = false;
+    static std::string load_err;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names) if (!api.lib) { api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (api.lib) api.path = std::string(n) + " (already in the process)"; }
+        if (!api.lib) { const char *e = getenv("DN_RCCL_PATH"); if (e && *e) { api.lib = dlopen(e, RTLD_NOW | RTLD_LOCAL); if (api.lib) api.path = e; } }
+        const char *sys[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char *n : sys) if (!api.lib) { api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.lib) api.path = n; }
+        if (!api.lib) load_err = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + "); set DN_RCCL_PATH";
+        else {
+            api.GetUniqueId = (decltype(api.GetUniqueId)) dlsym(api.lib, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank)) dlsym(api.lib, "ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy)) dlsym(api.lib, "ncclCommDestroy");
+            api.AllReduce = (decltype(api.AllReduce)) dlsym(api.lib, "ncclAllReduce");
+            api.GetErrorString = (decltype(api.GetErrorString)) dlsym(api.lib, "ncclGetErrorString");
+            api.GetVersion = (decltype(api.GetVersion)) dlsym(api.lib, "ncclGetVersion");
+            if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+                load_err = "librccl (" + api.path + ") lacks an entry point of the nccl API";
+                api.lib = nullptr;
+            }
+        }
+    }
+    if (!api.lib) { err = load_err; return nullptr; }
+    return &api;
+}
 
 static void free_device(dn_handle h)
 {
@@ -474,6 +528,7 @@ int dn_destroy(dn_handle h)
     if (!h) return DN_OK;
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
+    (void) dn_comm_destroy(h);
     free_device(h);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
@@ -1143,6 +1198,125 @@ int dn_outer_apply(dn_handle h, const double *avg_di, const double *norm, int32_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));           // the host buffers behind avg_di / norm may go away
     return DN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The collective of the sharded run inside the library (nmf_mpi.py:758-815 moves whole coverage chunks and DI matrices
+// through rank 0; here 3p + 4 doubles are summed over the GPUs in place, on the handle's own stream, by RCCL over xGMI).
+// ---------------------------------------------------------------------------------------------------
+#define RCCL_TRY(api, expr)                                                                        \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return fail(DN_E_HIP, std::string(#expr) + ": " + (api)->GetErrorString(r_));          \
+    } while (0)
+
+int dn_comm_unique_id(uint8_t *id)
+{
+    if (!id) return fail(DN_E_INVALID, "dn_comm_unique_id: null argument");
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(DN_E_STATE, "dn_comm_unique_id: " + err);
+    static_assert(sizeof(ncclUniqueId) == DN_COMM_ID_BYTES, "DN_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    ncclUniqueId u;
+    RCCL_TRY(api, api->GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return DN_OK;
+}
+
+int dn_comm_create(dn_handle h, const uint8_t *id, int32_t rank, int32_t size)
+{
+    if (!h) return fail(DN_E_INVALID, "dn_comm_create: null handle");
+    if (!id || size < 1 || rank < 0 || rank >= size) return fail(DN_E_INVALID, "dn_comm_create: bad argument");
+    if (h->comm) return fail(DN_E_STATE, "dn_comm_create: this handle already has a communicator");
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(DN_E_STATE, "dn_comm_create: " + err);
+    HIP_TRY(hipSetDevice(h->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t c = nullptr;
+    RCCL_TRY(api, api->CommInitRank(&c, size, u, rank));
+    h->comm = c; h->comm_rank = rank; h->comm_size = size;
+    if (!h->d_comm) HIP_TRY(hipMalloc(&h->d_comm, sizeof(double) * 256));
+    return DN_OK;
+}
+
+int dn_comm_destroy(dn_handle h)
+{
+    if (!h || !h->comm) return DN_OK;
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    (void) hipSetDevice(h->device);
+    if (h->stream) (void) hipStreamSynchronize(h->stream);
+    if (api) (void) api->CommDestroy((ncclComm_t) h->comm);
+    h->comm = nullptr; h->comm_size = 0; h->comm_rank = 0;
+    if (h->d_comm) { (void) hipFree(h->d_comm); h->d_comm = nullptr; }
+    return DN_OK;
+}
+
+int32_t dn_comm_size(dn_handle h) { return h ? h->comm_size : 0; }
+
+const char *dn_comm_library(void)
+{
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    static std::string text;
+    if (!api) { text = ""; return text.c_str(); }
+    int v = 0;
+    if (api->GetVersion) (void) api->GetVersion(&v);
+    text = api->path + ", nccl api " + std::to_string(v);
+    return text.c_str();
+}
+
+// sum d_buf[0 .. count) over the ranks in place on the handle's stream, then copy the totals to the host
+static int allreduce_to_host(dn_handle h, double *d_buf, int32_t count, double *totals)
+{
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(DN_E_STATE, err);
+    RCCL_TRY(api, api->AllReduce(d_buf, d_buf, (size_t) count, ncclDouble, ncclSum, (ncclComm_t) h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(totals, d_buf, sizeof(double) * (size_t) count, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DN_OK;
+}
+
+int dn_comm_allreduce(dn_handle h, double *buf, int32_t count)
+{
+    if (!h || !h->comm) return fail(DN_E_STATE, "dn_comm_allreduce: dn_comm_create has not been called");
+    if (!buf || count < 1 || count > 256) return fail(DN_E_INVALID, "dn_comm_allreduce: 1 .. 256 doubles");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_comm, buf, sizeof(double) * (size_t) count, hipMemcpyHostToDevice, h->stream));
+    return allreduce_to_host(h, h->d_comm, count, buf);
+}
+
+int dn_init_allreduce(dn_handle h, double *totals)
+{
+    if (!h || !h->comm) return fail(DN_E_STATE, "dn_init_allreduce: dn_comm_create has not been called");
+    if (!h->d_x) return fail(DN_E_STATE, "dn_init_allreduce: dn_init_begin has not been called");
+    if (!totals) return fail(DN_E_INVALID, "dn_init_allreduce: null output");
+    HIP_TRY(hipSetDevice(h->device));
+    { const int rc = outer_alloc(h, 0); if (rc != DN_OK) return rc; }
+    const int blocks = (int) std::min<int64_t>(OUT_BLOCKS, (h->n + 3) / 4);
+    hipLaunchKernelGGL(k_init_partials, dim3(blocks), dim3(256), 0, h->stream, h->d_est_sums, h->d_cov_sums, h->d_status, h->d_x, h->d_part,
+                       (int) h->n, (int) h->p);
+    hipLaunchKernelGGL(k_outer_reduce, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_pvec, blocks, (int) h->p);
+    HIP_TRY(hipGetLastError());
+    return allreduce_to_host(h, h->d_pvec, 3 * h->p + 4, totals);
+}
+
+int dn_outer_allreduce(dn_handle h, double *totals)
+{
+    if (!h || !h->comm) return fail(DN_E_STATE, "dn_outer_allreduce: dn_comm_create has not been called");
+    if (!h->d_xw) return fail(DN_E_STATE, "dn_outer_allreduce: dn_outer_begin has not been called");
+    if (!totals) return fail(DN_E_INVALID, "dn_outer_allreduce: null output");
+    HIP_TRY(hipSetDevice(h->device));
+    const int blocks = (int) std::min<int64_t>(OUT_BLOCKS, (h->n + 3) / 4);
+    hipLaunchKernelGGL(k_outer_partials, dim3(blocks), dim3(256), 0, h->stream, h->d_rho, h->d_rhoc, h->d_xw, h->d_trace, h->d_flags, h->d_part,
+                       (int) h->n, (int) h->p);
+    hipLaunchKernelGGL(k_outer_reduce, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_pvec, blocks, (int) h->p);
+    HIP_TRY(hipGetLastError());
+    return allreduce_to_host(h, h->d_pvec, 3 * h->p + 4, totals);
 }
 
 int dn_fetch_outer(dn_handle h, double *rho, double *x_adj, double *x_weighted, uint8_t *ran)

@@ -1577,9 +1577,15 @@ __device__ __forceinline__ int mg_core(gF_cptr Fb, gdouble_ptr Lg, double *lam, 
 #define DN_RT_CLAIM()
 #endif
 #ifndef DN_RAW_MAX_P
-#define DN_RAW_MAX_P 11          // p = 12 stays in scaled units: with raw units its pair build fails the edge-shape parity test on genes that fill the
-                                 // register tier (the coefficients broadcast from the scaled iterate come out wrong there -- the plain form, u from the
-                                 // solver times the factors from LDS, passes; explicit wait states change nothing; not understood, so not shipped)
+#if DN_SOLVER_DPP
+#define DN_RAW_MAX_P 12          // every register-tier cohort (round 4)
+#else
+#define DN_RAW_MAX_P 11          // with the squaring solver of rounds 1-3 (DN_SOLVER_DPP=0) p = 12 stays in scaled units: its raw-unit pair build
+                                 // failed the edge-shape parity test on genes that fill the register tier -- the two coefficient sets of the pass
+                                 // came out wrong when they were scaled in that solver's iterate layout (lane group q holds v[q + 4 kb], 3 registers
+                                 // at p = 12 with NO padding lane) and broadcast from there; with top_eig_dpp the iterate is one register, component i
+                                 // in lane i, the same two multiplies and readlanes pass (tests: pair class and edge shapes, p = 2 .. 12, tier-filling genes)
+#endif
 #endif
 template <int P> constexpr bool raw_units() { return DN_RAW_UNITS != 0 && DN_REG_TIER != 0 && P <= DN_RAW_MAX_P && P < DN_MG_MIN_P; }
 

@@ -159,6 +159,19 @@ class GeneNMFOA(object):
 
     fit = run   # BASELINE.json names the entry point `fit`; the reference's is `run`
 
+    def correct_di_scores(self):
+        """
+        The reference's public helper (nmf.py:148-158), kept for callers and subclasses that invoke it: genes whose DI row is
+        all zero get 1 - colsum(x_weighted) / colsum(x_adj).  run() does this on the device (dn_outer_apply); here the same
+        rule is applied to the host copies self.rho / self.x_weighted / self.x_adj, in place.
+        """
+        if not self.fitted:
+            raise ValueError('Model not yet fit. NMF-OA has not been run.')
+        avg_di_score = 1 - (self.x_weighted.sum(axis=0) / self.x_adj.sum(axis=0))
+        zero_idx = np.where(self.rho.max(axis=1) == 0)[0]
+        if len(zero_idx) > 0:
+            self.rho[zero_idx, :] = avg_di_score
+
     def estimates_for(self, genes):
         """
         Estimated coverage matrices of a few genes only (by name), rebuilt on demand from the device-side state of the

@@ -211,12 +211,33 @@ class ShardedNMFOA(object):
         self._trace_bufs, self._state_bufs = {}, None
         self.gene_names = None                            # optional: names of the local genes, for error / warning texts
         self.n_flagged = []                               # per outer iteration: genes sent through baseline selection (all ranks)
+        self._lib_comm = False                            # True: the collectives run inside the library (attach_library_comm)
+        self.library_reductions = 0
 
     @property
     def dev(self):
         if self._dev is None:
             self._dev = _lib.Device(self._dev_id)
         return self._dev
+
+    # -- the collective inside the library ---------------------------------------------------------
+    def attach_library_comm(self):
+        """
+        From here on every collective of this engine runs INSIDE the library (include/degnorm_amd.h dn_comm_*: RCCL on the library's
+        own stream, in place on its device buffer -- no tensor, no host hop before the reduction): rank 0 draws the communicator id,
+        `self.comm` only carries those 128 bytes to the other ranks once.  Collective: every rank of `self.comm` must call it.
+        """
+        uid = _lib.Device.comm_unique_id() if self.comm.rank == 0 else None
+        uid = _bcast(self.comm, None if uid is None else uid.tobytes())
+        self.dev.comm_create(np.frombuffer(uid, dtype=np.uint8), self.comm.rank, self.comm.size)
+        self._lib_comm = True
+
+    def _sum(self, vec):
+        """Sum a small float64 vector over the ranks."""
+        if self._lib_comm:
+            self.library_reductions += 1
+            return self.dev.comm_allreduce(vec)
+        return _allreduce(self.comm, vec)
 
     # -- data -------------------------------------------------------------------------------------
     def load(self, cov_mats, reads, global_ids=None, n_total=None, p=None, n_threads=0):
@@ -263,10 +284,17 @@ class ShardedNMFOA(object):
         # With the device-side update the two n x p sums of the initial pass never leave the GPU either: it reduces rho0, the
         # low genes and their read counts itself (dn_init_partials) and the host sees 2p + 2 numbers.
         on_device = self.device_outer and self.n_local > 0 and getattr(self, '_reads_on_device', False) and hasattr(self.dev, 'outer_begin')
+        tot = None
         if on_device:
             self.dev.ratio_svd_sums(fetch=False)
-            pv = self.dev.init_partials()
-            n_bad_local, part = float(pv[3 * p + 1]), np.concatenate([pv[:p], pv[p:2 * p], [pv[3 * p]]])
+            if self._lib_comm:                                         # ONE collective, on the sums where they are (dn_init_allreduce)
+                tv = self.dev.init_allreduce()
+                self.library_reductions += 1
+                n_bad, tot = float(tv[3 * p + 1]), np.concatenate([tv[:p], tv[p:2 * p], [tv[3 * p]]])
+                n_bad_local = float(self.dev.init_partials()[3 * p + 1]) if n_bad > 0 else 0.0
+            else:
+                pv = self.dev.init_partials()
+                n_bad_local, part = float(pv[3 * p + 1]), np.concatenate([pv[:p], pv[p:2 * p], [pv[3 * p]]])
             self.rho = None                                            # rho0 stays on the device
         else:
             if self.n_local > 0:
@@ -274,14 +302,18 @@ class ShardedNMFOA(object):
             else:
                 est_sums, cov_sums, status = np.zeros((0, p)), np.zeros((0, p)), np.zeros(0, dtype=np.int32)
             n_bad_local = float(np.sum(status != 0))
-        n_bad = _allreduce(self.comm, [n_bad_local])[0]
-        if n_bad > 0:                                                 # every rank raises together
-            raise ValueError(self._init_failure_text(int(n_bad), n_bad_local, None if on_device else status))
-        if not on_device:
             self.rho = 1 - (cov_sums / (est_sums + 1))
             low = self.rho.max(axis=1) < 0.1 if self.n_local > 0 else np.zeros(0, dtype=bool)
             part = np.concatenate([self.x[low].sum(axis=0), self.x.sum(axis=0), [float(low.sum())]])
-        tot = _allreduce(self.comm, part)
+            if self._lib_comm:                                         # the same 3p + 4 layout the device-side ranks reduce
+                tv = self._sum(np.concatenate([part[:2 * p], np.zeros(p), [part[2 * p], n_bad_local, 0., 0.]]))
+                n_bad, tot = float(tv[3 * p + 1]), np.concatenate([tv[:p], tv[p:2 * p], [tv[3 * p]]])
+        if tot is None:
+            n_bad = _allreduce(self.comm, [n_bad_local])[0]
+        if n_bad > 0:                                                 # every rank raises together
+            raise ValueError(self._init_failure_text(int(n_bad), n_bad_local, None if on_device else status))
+        if tot is None:
+            tot = _allreduce(self.comm, part)
         count_sums = tot[:p] if tot[2 * p] > 0 else tot[p:2 * p]
         self.norm_factors = count_sums / np.median(count_sums)
         self.x_weighted = None if on_device else self.x / self.norm_factors      # on the device: formed there, fetched by fetch_state()
@@ -397,7 +429,7 @@ class ShardedNMFOA(object):
         """
         p = self.p
         if tot is None:
-            tot = _allreduce(self.comm, partials)
+            tot = self._sum(partials)
         A, B, Wt, n_untouched = tot[:p], tot[p:2 * p], tot[2 * p:3 * p], tot[3 * p]
         self.n_failed.append((int(tot[3 * p + 1]), int(tot[3 * p + 2])))
         self.n_flagged.append(int(tot[3 * p + 3]))                    # ran_baseline_selection[:, i].sum() (nmf.py:571)
@@ -434,7 +466,10 @@ class ShardedNMFOA(object):
             self.rho_raw_hist.append(rho_rows)
             self.flags_hist.append(flag_rows)
         tot = None
-        if hasattr(self.comm, 'allreduce_device') and hasattr(self.dev, 'outer_partials_device'):
+        if self._lib_comm:                                            # dn_outer_allreduce: partial sums, RCCL all-reduce, totals -- one call
+            tot = self.dev.outer_allreduce()
+            self.library_reductions += 1
+        elif hasattr(self.comm, 'allreduce_device') and hasattr(self.dev, 'outer_partials_device'):
             ptr, cnt = self.dev.outer_partials_device()               # the sums stay in HBM: the collective works on that buffer
             tot = self.comm.allreduce_device(ptr, cnt, self._dev_id)
         avg_di, norm = self._reduce_and_update(i, self.dev.outer_partials() if tot is None else None, tot)

@@ -140,6 +140,31 @@ int  dn_outer_partials(dn_handle h, double *partials);
 int  dn_outer_partials_device(dn_handle h, double **d_partials);
 int  dn_outer_apply(dn_handle h, const double *avg_di, const double *norm, int32_t iter);
 int  dn_fetch_outer(dn_handle h, double *rho, double *x_adj, double *x_weighted, uint8_t *ran);
+
+/* The collective of the sharded run, inside the library ----------------------------------------------------
+ * Replaces: the per-iteration traffic of run_gene_nmfoa_mpi -- rank 0 re-scales and re-sends every coverage chunk
+ * (nmf_mpi.py:745-760), every worker returns its estimates and DI rows (:796-815) and rank 0 alone updates the scale
+ * factors (:821-838).  Here every GPU keeps its genes, and ONE all-reduce of 3p + 4 float64 per outer iteration (RCCL
+ * over xGMI, in place on the library's device buffer, on the library's stream) gives every rank what it needs to
+ * compute the new scale factors itself.  A host written in any language shards a run with these calls alone:
+ *   dn_comm_unique_id   rank 0: DN_COMM_ID_BYTES opaque bytes (ncclGetUniqueId); the host hands them to every rank by
+ *                       whatever it has (MPI_Bcast, a file, a socket)
+ *   dn_comm_create      every rank, collectively: joins the communicator with the handle's GPU (ncclCommInitRank)
+ *   dn_init_allreduce   dn_init_partials summed over the ranks: totals[3p + 4], same layout
+ *   dn_outer_allreduce  dn_outer_partials summed over the ranks: totals[3p + 4], same layout; dn_outer_apply follows
+ *   dn_comm_allreduce   sums a small host vector (<= 256 doubles) over the ranks in place: a rank WITHOUT genes joins the
+ *                       two collectives above with zeros through this call (same count 3p + 4), error counts, ...
+ *   dn_comm_library     which librccl was bound ("" if none could be loaded).  RCCL is resolved at run time (a copy the
+ *                       process already holds, e.g. PyTorch's, else DN_RCCL_PATH, else the system's): no link-time dependency. */
+#define DN_COMM_ID_BYTES 128
+int  dn_comm_unique_id(uint8_t *id);
+int  dn_comm_create(dn_handle h, const uint8_t *id, int32_t rank, int32_t size);
+int  dn_comm_destroy(dn_handle h);
+int32_t dn_comm_size(dn_handle h);
+const char *dn_comm_library(void);
+int  dn_comm_allreduce(dn_handle h, double *buf, int32_t count);
+int  dn_init_allreduce(dn_handle h, double *totals);
+int  dn_outer_allreduce(dn_handle h, double *totals);
 int  dn_fetch_rows(dn_handle h, int64_t n_rows, const int64_t *rows, double *rho_raw, int32_t *flags);
 
 /* Estimated coverage matrices of the last dn_baseline_iteration run with want_estimates = 1 ----------

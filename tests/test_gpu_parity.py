@@ -125,7 +125,7 @@ def test_run_config2_subset_vs_reference_golden():
     assert rel.max() < 1e-5
 
 
-def test_run_config2_deep_vs_reference_golden(device):
+def test_run_config2_deep_vs_reference_golden(device, oracle):
     """
     The headline configuration at depth: 256 genes x BASELINE's 5 outer iterations x T = 100 against the REAL reference
     (tests/golden/run_c2_deep.npz, ~17 min of reference time): both gene classes of the device run concurrently,
@@ -168,7 +168,21 @@ def test_run_config2_deep_vs_reference_golden(device):
     print('deep golden, self-consistent run: {0} of {1} genes took another branch (tie on the 0.1 x max threshold); '
           'their max |dDI| vs the reference = {2:.3e}; ids {3}'.format(int(flipped.sum()), len(covs), d_flip, np.flatnonzero(flipped).tolist()))
     assert flipped.sum() <= 2
-    assert d_flip <= 0.9                     # a DI score lives in [0, 0.9]; the flipped gene is a different, equally valid branch
+    # A flipped gene must be EXPLAINED: with the scale factors this run itself used in every iteration, the pinned oracle takes the
+    # device's branch and lands on the device's DI (so the only difference to the reference is the last bits of a scale factor
+    # deciding a 10 x == max tie) -- and a tie moves one column of a thousand: the DI may not move by more than a few per cent.
+    if flipped.any():
+        ids = np.flatnonzero(flipped)
+        sub = [covs[k] for k in ids]
+        device.upload(sub)
+        for i in range(n_it):
+            sc = m._engine.scale_hist[i]
+            rho_d, flags_d, tr_d = device.baseline_iteration(sc, nmf_iter=int(G['nmf_iter']))
+            rho_o, flags_o, tr_o, _ = oracle.baseline_batch(sub, sc, oracle.make_params(nmf_iter=int(G['nmf_iter'])))
+            np.testing.assert_array_equal(tr_d[:, :7], tr_o[:, :7])
+            np.testing.assert_array_equal(tr_d[:, 1], m.traces[i][ids, 1])
+            np.testing.assert_allclose(rho_d, rho_o, rtol=RTOL, atol=ATOL)
+    assert d_flip <= 0.05
     ok = ~flipped
     tol = RTOL if not flipped.any() else 1e-5
     np.testing.assert_array_equal(m.ran_baseline_selection[ok], G['ran_baseline_selection'][ok])
@@ -457,7 +471,7 @@ def test_full_size_head_vs_oracle(device, oracle):
     np.testing.assert_array_equal(trace[:, :7], trace_o[:, :7])
 
 
-@pytest.mark.parametrize('p', [2, 3, 7, 8, 9, 11, 12, 13, 14, 16, 17, 20, 24, 31, 32, 33, 40, 48, 49, 64])
+@pytest.mark.parametrize('p', [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 20, 24, 31, 32, 33, 40, 48, 49, 64])
 def test_sample_counts_and_edge_shapes_vs_oracle(device, oracle, p):
     """Every compiled sample count family (templated 2..48: one / several Gram sweeps, MFMA / row solver; run-time-p above)
     on ragged / tiny / single-gene inputs."""
@@ -485,13 +499,16 @@ def test_sample_counts_and_edge_shapes_vs_oracle(device, oracle, p):
     np.testing.assert_allclose(rho1[0], oracle.baseline_batch(covs[:1], scale, oracle.make_params(nmf_iter=12))[0][0], rtol=1e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize('p', [8, 9, 10, 11, 12])
+@pytest.mark.parametrize('p', list(range(2, 13)))
 def test_pair_class_agrees_with_narrow_class_and_oracle(oracle, monkeypatch, p):
     """
     The pair class (one wavefront per gene, two genes per 128-thread workgroup: the DN_PAIR build, csrc/dn_kernels.hpp) against
     the same genes on the narrow class (DN_TINY_LEN=0) and against the oracle: genes below and above a wavefront's on-chip
     capacity (register tier only / + LDS tier / + spill tier), an odd number of them (the last workgroup has one idle
-    unit), one with a count beyond 16 bits (the variant that re-reads its counts), estimates included.
+    unit), one with a count beyond 16 bits (the variant that re-reads its counts), estimates included.  Every sample count with
+    a pair build (p = 2 .. 12; round 4: all of them keep the T loop's state in raw count units), and for each of them genes whose
+    active columns fill the register tier EXACTLY, one column less and one more -- of a wavefront (pair class: the straight-line
+    body starts there) and of a 128-thread workgroup (narrow class).
     """
     from degnorm_amd import _lib
     covs = [synth.synth_gene(21, g, p, lo, hi)[0] for g, (lo, hi) in enumerate(
@@ -499,6 +516,11 @@ def test_pair_class_agrees_with_narrow_class_and_oracle(oracle, monkeypatch, p):
     big = np.array(covs[2], dtype=float)
     big[0, :7] = 70000.0                                                   # not packable into 16 bits
     covs.append(big)
+    rt_cols = min(12, 256 // (2 * p + (p + 1) // 2))                       # dn_kernels.hpp rt_cols<P, X16 = true>
+    rng = np.random.default_rng(500 + p)
+    for cap in (rt_cols * 64, rt_cols * 128):
+        for L in (cap - 1, cap, cap + 1):                                  # flat, deep coverage: every base is an active column
+            covs.append(rng.poisson(np.outer(rng.uniform(150., 400., p), np.ones(L))).astype(float))
     assert len(covs) % 2 == 0
     covs = covs[:-1] + [covs[-1]] + [synth.synth_gene(22, 0, p, 300, 300)[0]]      # odd count in the pair class
     scale = np.linspace(0.85, 1.25, p)
@@ -518,6 +540,7 @@ def test_pair_class_agrees_with_narrow_class_and_oracle(oracle, monkeypatch, p):
             dev.close()
     assert out['0'][4] == 0 and out['0'][5] == ''
     assert out[None][4] > 1200 and out[None][5] == 'k_baseline<{0},64>'.format(p)
+    assert sum(1 for c in covs if c.shape[1] <= out[None][4]) >= 20        # the pair class got its genes, the tier-filling ones among them
     rho_o, flags_o, trace_o, est_o = oracle.baseline_batch(covs, scale, oracle.make_params(nmf_iter=T), want_estimates=True)
     for key in ('0', None):
         rho, flags, trace, est = out[key][:4]
@@ -923,3 +946,64 @@ def test_randomised_differential_rounds(oracle):
         bad += b
     assert genes > 800
     assert bad == 0, '\n'.join(l for l in lines if 'mismatching' in l and not l.rstrip().endswith('-> 0 mismatching genes') or l.startswith('      '))
+
+
+def test_pileup_genes_vs_reference_golden(oracle):
+    """
+    tests/golden/pileup.npz (round 4, generated with the reference): read pile-up coverage -- reads of 75-150 bases stacked into
+    piecewise-constant small integers, the input kind DegNorm really sees (reads.py:714,773) and the one full of exact ties
+    (10 x == max in the high-coverage test, equal bin means, exact-zero residuals).  120 genes, p = 4 / 6 / 10, T = 20 / 100, each
+    stable over three runs of the reference: the device's nmf() call sequence, flag, DI and estimate row sums against the
+    reference's, gene by gene with the gene's own scale factors.
+    """
+    from test_oracle_golden import pileup_golden_cases
+    from degnorm_amd import _lib
+    n = n_loop = 0
+    dev = _lib.Device(0)
+    try:
+        for c in pileup_golden_cases():
+            dev.upload([c['x']])
+            rho, flags, trace = dev.baseline_iteration(c['scale'], nmf_iter=c['T'], want_estimates=True)
+            est = dev.fetch_estimates()
+            msg = 'pileup golden gene %d (kind %d, p = %d, T = %d, kernel %s)' % (c['k'], c['kind'], c['p'], c['T'], dev.main_kernel_name())
+            assert trace[0, 6] == 0, msg
+            assert trace[0, 1] == len(c['calls']) and trace[0, 2] == c['calls'].sum(), msg
+            assert bool(flags[0]) == c['flag'], msg
+            np.testing.assert_allclose(rho[0], c['rho'], rtol=1e-8, atol=1e-10, err_msg=msg)
+            np.testing.assert_allclose(est[0].sum(axis=1), c['est_rowsum'], rtol=1e-8, atol=1e-8, err_msg=msg)
+            n += 1; n_loop += int(c['flag'])
+    finally:
+        dev.close()
+    assert n >= 100 and n_loop >= 40
+
+
+def test_pileup_run_vs_reference_golden(device):
+    """
+    The whole chain on pile-up coverage against the reference's own run (48 genes, p = 6, 3 outer iterations, T = 100):
+    (a) every iteration driven with the scale factors the reference used -- exact branch traces on every gene;
+    (b) the self-consistent GeneNMFOA.fit(): flipped genes (a tie decided by the last bit of a scale factor) are counted, and a
+        flipped gene's DI must stay within the distance its own neighbouring branch allows -- here: none may flip at all, the
+        fixture's scale factors are reproduced to 1e-9 or the test says which gene moved.
+    """
+    from collections import OrderedDict
+    from degnorm_amd.nmf import GeneNMFOA
+    from test_oracle_golden import pileup_run_inputs
+    G = golden('pileup')
+    covs, reads = pileup_run_inputs(G)
+    device.upload(covs)
+    for i in range(3):
+        rho, flags, trace = device.baseline_iteration(G['run_scale_hist'][i], nmf_iter=100)
+        np.testing.assert_array_equal(trace[:, 1], G['run_n_calls'][i])
+        np.testing.assert_array_equal(trace[:, 2], G['run_sum_cols'][i])
+        np.testing.assert_array_equal(flags, G['run_flags'][:, i])
+        np.testing.assert_allclose(np.clip(rho, 0., 0.9), G['run_rho_hist'][i], rtol=RTOL, atol=ATOL)
+    m = GeneNMFOA(degnorm_iter=3, nmf_iter=100)
+    m.fit(OrderedDict(('pileup_%06d' % g, c) for g, c in zip(G['run_gene_ids'], covs)), reads)
+    flipped = np.zeros(len(covs), dtype=bool)
+    for i in range(3):
+        flipped |= (m.traces[i][:, 1] != G['run_n_calls'][i]) | (m.traces[i][:, 2] != G['run_sum_cols'][i])
+    assert not flipped.any(), 'pile-up genes that took another branch in the self-consistent run: %s' % np.flatnonzero(flipped).tolist()
+    np.testing.assert_array_equal(m.ran_baseline_selection, G['run_flags'])
+    np.testing.assert_allclose(m.rho, G['run_rho'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(m.x_adj, G['run_x_adj'], rtol=RTOL)
+    np.testing.assert_allclose(m.scale_factors, G['run_scale_factors'], rtol=RTOL)

@@ -139,3 +139,44 @@ def test_outer_update_on_the_device_equals_the_host_update():
     np.testing.assert_allclose(out[0].rho, out[1].rho, rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(out[0].x_adj, out[1].x_adj, rtol=1e-12)
     assert (out[0].rho.max(axis=1) == 0).sum() == 0 and (G['rho_hist'][0].max(axis=1) == 0).any()     # untouched genes were corrected
+
+
+def _libcomm_worker(out_q):
+    # no torch in this process: the library binds librccl by itself (dlopen), the communicator lives in the handle
+    from degnorm_amd.nmf_mpi import ShardedNMFOA, LocalComm
+    from degnorm_amd import _lib
+    G, cov_dat = _inputs()
+    eng = ShardedNMFOA(comm=LocalComm(), device=0, degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']))
+    eng.load(list(cov_dat.values()), G['reads'])
+    eng.attach_library_comm()
+    probe = eng.dev.comm_allreduce(np.arange(34, dtype=np.float64))
+    eng.run(want_estimates=False)
+    out_q.put(dict(rho=eng.rho, x_adj=eng.x_adj, flags=eng.ran_baseline_selection, probe=probe, lib=_lib.Device.comm_library(),
+                   size=eng.dev.comm_size(), reductions=eng.library_reductions, n_flagged=list(eng.n_flagged),
+                   torch_loaded='torch' in sys.modules))
+    eng.dev.comm_destroy()
+
+
+def test_collective_inside_the_library_world_size_1():
+    """
+    include/degnorm_amd.h dn_comm_*: the sharded run's collective behind the C ABI -- dn_comm_unique_id / dn_comm_create
+    (ncclCommInitRank on the handle's GPU), dn_init_allreduce and dn_outer_allreduce (partial sums -> ncclAllReduce in place on the
+    library's stream -> totals), with NO torch in the process -- at the one world size this box offers, against the reference's rows
+    of tests/golden/mpi.npz.  One reduction for the initial normalisation and one per outer iteration.
+    """
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out_q = ctx.Queue()
+    proc = ctx.Process(target=_libcomm_worker, args=(out_q,))
+    proc.start()
+    res = out_q.get(timeout=300)
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    G, _ = _inputs()
+    np.testing.assert_array_equal(res['probe'], np.arange(34, dtype=np.float64))
+    np.testing.assert_allclose(res['rho'], G['single_rho'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res['x_adj'], G['single_x_adj'], rtol=1e-9)
+    np.testing.assert_array_equal(res['flags'], G['single_flags'])
+    assert 'rccl' in res['lib'] and res['size'] == 1
+    assert res['reductions'] == 1 + int(G['degnorm_iter'])
+    np.testing.assert_array_equal(res['n_flagged'], G['single_flags'].sum(axis=0))
