@@ -54,7 +54,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2
 # back-to-back dependent FMAs -- at 4.08 cycles, against the 4 of the peak above (the 4.22 of round 2's clock_issue.hip included the
 # scalar overhead of its loop).  The kernel runs one wave per SIMD, so a moved dword costs as much as an fp64 FMA.
 FP64_ISSUE_CYCLES_1WAVE = 4.08
-ROUND = 'round3'
+ROUND = 'round4'
 REFERENCE_PY_GENES_PER_S_PER_THREAD = 0.18    # the reference itself (n_jobs = 1) on config-2-like genes, 5 iterations
 
 
@@ -324,6 +324,37 @@ def tie_sensitive_genes(packed, lengths, p, scale):
                     'their branch is decided by round-off of the scale factors (nmf.py:76), in the reference too'}
 
 
+def pileup_parity(device, p, scale, nmf_iter, n):
+    """
+    Read pile-up coverage (synth.pileup_gene: reads of 75-150 bases stacked into piecewise-constant small integers -- DegNorm's
+    real input kind, pinned with the reference in tests/golden/pileup.npz) through one outer iteration on the device and on the
+    oracle with the run's final scale factors: branch flips, DI distance, and how many of these genes are tie-sensitive
+    (a column within 4 ulp of the 0.1 x max F threshold) -- on small-integer coverage 10 x == max ties are the rule.
+    """
+    from oracle import oracle as orc
+    from degnorm_amd import synth, _lib
+    covs = [synth.pileup_gene(13, g, p, 300, 3000)[0] for g in range(n)]
+    dev = _lib.Device(device)
+    try:
+        dev.upload(covs)
+        rho_d, flags_d, tr_d = dev.baseline_iteration(scale, nmf_iter=nmf_iter)
+    finally:
+        dev.close()
+    t0 = time.time()
+    rho_o, flags_o, tr_o, _ = orc.baseline_batch(covs, scale, orc.make_params(nmf_iter, 20, 50, 1, False), n_threads=host_cores())
+    flips = np.any(tr_d[:, :7] != tr_o[:, :7], axis=1) | (flags_d != flags_o)
+    ok = ~flips
+    d = np.abs(rho_d - rho_o)
+    packed = np.concatenate([c.astype(np.float32).ravel() for c in covs])
+    ties = tie_sensitive_genes(packed, np.array([c.shape[1] for c in covs]), p, scale)
+    return {'genes': n, 'branch_flips': int(flips.sum()), 'max_rel_di': float((d[ok] / np.maximum(np.abs(rho_o[ok]), 1e-6)).max()) if ok.any() else None,
+            'flipped_max_abs_di': float(d[flips].max()) if flips.any() else 0.0,
+            'genes_through_the_drop_loop': int((tr_o[:, 1] > 1).sum()), 'tie_sensitive_genes': ties['genes'], 'tie_sensitive_columns': ties['columns'],
+            'oracle_s': time.time() - t0,
+            'what': 'synth.pileup_gene(13, g, p) g < n: one outer iteration at the run\'s final scale factors, device vs oracle; the same '
+                    'generator is pinned with the reference (three stable runs per gene) in tests/golden/pileup.npz'}
+
+
 def parity_sample(lengths, k):
     """Genes at evenly spaced length quantiles: every gene class and the whole work queue."""
     n = len(lengths)
@@ -443,6 +474,13 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
     t_up = time.time()
     eng.load_packed(packed, lengths, p, reads, global_ids=np.asarray(my_genes, dtype=np.int64), n_total=n_genes)
     t_up = time.time() - t_up
+    rowmax_ms = eng.dev.last_rowmax_ms() if eng.n_local > 0 else 0.0
+    lib_comm = None
+    if ctx['rccl_ranks'] is not None and not ctx['rehearsal'] and not args.torch_collective:
+        # the collective of the step runs INSIDE the library (dn_comm_*: ncclAllReduce on the library's own stream, in place on its
+        # device buffer); torch.distributed only carried the 128-byte communicator id to the ranks and times the barrier around the clock
+        eng.attach_library_comm()
+        lib_comm = eng.dev.comm_library()
     keep_packed = rank == 0 and world == 1 and config == 'c2'              # the float64 dict of end_to_end / the tie count are made from it
     if not keep_packed:
         packed = None
@@ -468,6 +506,9 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
 
     split = eng.dev.split_length() if eng.n_local > 0 else 0
     tiny = eng.dev.tiny_length() if split > 0 else 0
+    # the measured stream-read ceiling of this device, beside the data sheet's 8 TB/s (a read-only kernel with four
+    # 16-byte loads per lane in flight over 1 GiB, best of 5; outside the clock)
+    stream_gbps = eng.dev.measure_read_gbps(1 << 30, 5) if (rank == 0 and eng.n_local > 0) else None
     wide = lengths > split if split > 0 else np.ones(len(lengths), dtype=bool)
     pair = (lengths <= tiny) & ~wide                                    # class 2: one wavefront per gene, two genes per workgroup
     kernel_ms, narrow_ms, pair_ms, all_traces, eng_span = [], [], [], [], []
@@ -516,7 +557,9 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
                    'step': 'initial pass + {0} outer iterations + D2H of the final rho / x_adj / x_weighted / flags '
                            '(fetch_state {1:.2f} ms per step)'.format(args.iters, 1e3 * float(np.mean(fetch_s)))},
         'rccl_ranks': ctx['rccl_ranks'],
-        'rccl': dict(ctx['rccl'] or {}, all_reduce_on_device_buffer=getattr(comm, 'device_reductions', 0) > 0) if ctx['rccl'] else None,
+        'rccl': dict(ctx['rccl'] or {}, all_reduce_on_device_buffer=(getattr(comm, 'device_reductions', 0) > 0 or eng.library_reductions > 0),
+                     collective_inside_library=lib_comm is not None, library_rccl=lib_comm,
+                     library_reductions_per_step=(eng.library_reductions // max(1, steps + warmup)) if lib_comm else 0) if ctx['rccl'] else None,
     }
     if config == 'c2':
         # Three gene classes = three kernels per outer iteration on three streams: class 0 (genes longer than the split
@@ -531,14 +574,24 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
         mask, avg_ms, name_d = cls_mask[dom], cls_ms[dom], eng.dev.class_kernel_name(dom)
         span_ms = float(np.mean(eng_span)) if eng_span else max(cls_ms)
 
+        # fp64 vector work of the inner passes, per column and inner iteration: u.a (2p), the update (5p), the Gram update
+        # (p(p+1)) -- and the 1/s scaling (p) only where the pass still has it: the register-tier cohorts (p <= 12) keep the T
+        # loop's state in raw count units (csrc/dn_kernels.hpp DN_RAW_MAX_P).  Wave-instructions per 64 columns: p(p+1)/2 + 4p
+        # FMA / max (+ p mul when scaled) + p cvt.
+        raw_units = p <= 12
+        flop_col = p * p + (8.0 if raw_units else 9.0) * p
+        instr_col = p * (p + 1) / 2.0 + (5.0 if raw_units else 6.0) * p
+
         def work(m):
-            # fp64 vector work of the inner passes: per column and inner iteration u.a (2p), the update (5p), the Gram
-            # update (p(p+1)) and the 1/s scaling (p); wave-instructions: p(p+1)/2 + 5p FMA/max/mul + p cvt per 64 columns
             col_iters = float(np.mean([float(tr[m, 2].astype(np.float64).sum()) * args.nmf_iter for tr in all_traces]))
-            return col_iters * (p * p + 9.0 * p), col_iters / 64.0 * (p * (p + 1) / 2.0 + 6.0 * p)
+            return col_iters * flop_col, col_iters / 64.0 * instr_col
         flop_d, instr_d = work(mask)
         flop_a, instr_a = work(np.ones(len(lengths), dtype=bool))
         alg_all = float(np.mean([algorithmic_bytes(tr, lengths, p, args.nmf_iter) for tr in all_traces]))
+        # ALL kernels' work over the sweep: the longer of the dominant launch and the first-launch-to-last-end span (they agree
+        # when the dominant kernel is the last to end, which is how the classes are scheduled; if they ever do not, the span is right)
+        kernel_avg_ms = avg_ms
+        avg_ms = max(avg_ms, span_ms)
         tflops = flop_a / (avg_ms * 1e-3) / 1e12
         simd_cycles = lambda ms: ms * 1e-3 * 2.4e9 * 256 * 4
         issue_peak = FP64_VECTOR_PEAK_TFLOPS * 4.0 / FP64_ISSUE_CYCLES_1WAVE
@@ -552,13 +605,13 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
             'what': 'fp64 vector work of ALL genes (every class kernel) / average launch duration of the dominant kernel: the '
                     'class kernels are launched back to back on their own streams, the dominant one is the last to end, so its '
                     'launch spans the whole sweep and the other kernels run INSIDE that window',
-            'kernel': name_d, 'avg_launch_ms': avg_ms, 'launches_timed': len(kernel_ms),
+            'kernel': name_d, 'avg_launch_ms': kernel_avg_ms, 'sweep_ms': avg_ms, 'launches_timed': len(kernel_ms),
             'genes_in_kernel': int(mask.sum()), 'split_length': split, 'pair_length': tiny,
             'concurrent_kernels': [{'kernel': eng.dev.class_kernel_name(c), 'genes': int(cls_mask[c].sum()),
                                     'avg_launch_ms': cls_ms[c]} for c in others],
             'sweep_span_ms': span_ms,
-            'dominant_kernel_own_work': {'fp64_tflops': flop_d / (avg_ms * 1e-3) / 1e12,
-                                         'frac': flop_d / (avg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            'dominant_kernel_own_work': {'fp64_tflops': flop_d / (kernel_avg_ms * 1e-3) / 1e12,
+                                         'frac': flop_d / (kernel_avg_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                                          'note': 'only the dominant kernel\'s genes over its launch duration (it has the chip to itself '
                                                  'for only part of that time)'},
             'issue_ceiling': {'peak': issue_peak, 'frac': tflops / issue_peak,
@@ -567,7 +620,8 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
                                       .format(FP64_ISSUE_CYCLES_1WAVE)},
             'valu_issue_slots': {'wave_instructions': instr_a, 'slots_frac': instr_a * 4.0 / simd_cycles(avg_ms),
                                  'what': 'fp64 wave-instructions of the passes x 4 cycles / (sweep time x 2.4 GHz x 1024 SIMDs)'},
-            'flop_per_column_iteration': p * p + 9.0 * p,
+            'flop_per_column_iteration': flop_col, 'raw_count_units': raw_units,
+            'stream_read_ceiling_gbps': stream_gbps,
             'traffic': traffic_all, 'traffic_info': tinfo,
             'traffic_per_kernel': dict({name_d: traffic}, **traffic_o),
             'traffic_rate_gbps': (traffic_all / (avg_ms * 1e-3) / 1e9) if traffic_all else None,
@@ -594,6 +648,12 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
             'frac': alg_init / (init_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'traffic': None,
             'kernel': eng.dev.init_kernel_name(), 'avg_launch_ms': init_avg, 'launches_timed': len(init_ms),
             'algorithmic_bytes_per_launch': alg_init,
+            'stream_read_ceiling_gbps': stream_gbps,
+            'frac_of_stream_read_ceiling': (alg_init / (init_avg * 1e-3) / 1e9 / stream_gbps) if stream_gbps else None,
+            'row_maxima_kernel': {'kernel': 'k_row_max', 'ms': rowmax_ms, 'bytes': 4.0 * p * float(lengths.sum()),
+                                  'gbps': (4.0 * p * float(lengths.sum()) / (rowmax_ms * 1e-3) / 1e9) if rowmax_ms > 0 else None,
+                                  'frac_of_hbm_peak': (4.0 * p * float(lengths.sum()) / (rowmax_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if rowmax_ms > 0 else None,
+                                  'what': 'once per upload (outside the step): one read of the packed coverage for the p row maxima of every gene'},
             'share_of_step': {'initial_pass_ms': init_avg, 'iteration_kernel_ms': avg_ms * args.iters, 'step_ms': dt / steps * 1e3},
             'iteration_kernel': iteration_kernel_bound(eng, name0, avg_ms, len(kernel_ms), sampled, calls, solves, steps_pw, lengths, p, rate),
             'shortcut': 'max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i): per-iteration full-length scans removed; without it SURVEY 8(d) '
@@ -618,6 +678,8 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
         out['cpu_baseline'] = None
     if keep_packed and out['parity'] is not None and n_genes == cfg['n_genes']:
         out['parity']['tie_sensitive'] = tie_sensitive_genes(packed, lengths, p, final_scale)
+    if world == 1 and config == 'c2' and out['parity'] is not None and n_cpu > 0:
+        out['parity']['pileup'] = pileup_parity(local_rank, p, final_scale, args.nmf_iter, 384)
     if keep_packed and want_e2e:
         out['end_to_end'] = end_to_end(packed, lengths, p, reads, args.iters, args.nmf_iter, rate, local_rank)
     return out
@@ -730,6 +792,9 @@ def parse(argv=None):
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the GeneNMFOA.fit() end-to-end timing (config 2, N = 1)')
     ap.add_argument('--no-also', action='store_true', help='skip the config-4 measurement appended to the default config-2 line')
     ap.add_argument('--no-rccl', action='store_true', help='N = 1 without torchrun: do not open a one-rank RCCL process group')
+    ap.add_argument('--torch-collective', action='store_true',
+                    help='run the per-iteration all-reduce through torch.distributed on the library\'s device buffer (round 3) instead of '
+                         'inside the library (dn_comm_*, the default with the nccl backend)')
     ap.add_argument('--dump-traces', default='', help='write the per-gene device counters of the last step to FILE.<config>.npz')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='collective backend of the ranks: nccl = RCCL (the measured path); gloo only to rehearse N > 1 on ONE GPU '

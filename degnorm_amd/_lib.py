@@ -89,6 +89,10 @@ def load(build_if_missing=False):
     lib.dn_synchronize.argtypes = [vp]
     lib.dn_measure_copy_gbps.argtypes = [vp, i64, c.c_int]
     lib.dn_measure_copy_gbps.restype = dbl
+    lib.dn_last_rowmax_ms.argtypes = [vp]
+    lib.dn_last_rowmax_ms.restype = dbl
+    lib.dn_measure_read_gbps.argtypes = [vp, i64, c.c_int]
+    lib.dn_measure_read_gbps.restype = dbl
     lib.dn_assemble_coverage.argtypes = [c.c_int, i64, i32, P(i64), P(vp), P(vp), i64, P(i64), i64, P(i32), P(i64), P(i64), P(i32),
                                          P(c.c_float), P(dbl)]
     lib.dn_assemble_last_error.restype = c.c_char_p
@@ -417,3 +421,10 @@ class Device:
 
     def measure_copy_gbps(self, nbytes=1 << 30, reps=5):
         return float(self.lib.dn_measure_copy_gbps(self.h, int(nbytes), int(reps)))
+
+    def measure_read_gbps(self, nbytes=1 << 30, reps=5):
+        """Stream-read ceiling of the device (GB/s)."""
+        return float(self.lib.dn_measure_read_gbps(self.h, int(nbytes), int(reps)))
+
+    def last_rowmax_ms(self):
+        return float(self.lib.dn_last_rowmax_ms(self.h))

@@ -99,7 +99,16 @@ const KernelSet *kernel_set_for(int p)
 
 // Row maxima of the raw coverage, once per upload: max_j fl(x_ij / s_i) = fl((max_j x_ij) / s_i) for s_i > 0, so the
 // 0.1 * max(F) threshold of get_high_coverage_idx (nmf.py:66-76) needs these p numbers per gene instead of a scan of
-// the whole scaled matrix in every outer iteration (SURVEY 8(d), config-4 regime note).  One workgroup per gene.
+// the whole scaled matrix in every outer iteration (SURVEY 8(d), config-4 regime note).  One workgroup per gene, one wave per
+// row at a time.  Round 4: a pure max-reduce has to stream -- a wave keeps FOUR 16-byte loads per lane in flight (4 KiB per wave
+// and trip; rows are only 4-byte aligned, so a scalar head brings the wave to a 16-byte boundary first) instead of one dword
+// (round 3: 2.77 TB/s on config 4's 27.5 GB).
+__device__ __forceinline__ void row_max_acc(float v, float &m, bool &ok)
+{
+    m = fmaxf(m, v);
+    ok = ok && (v >= 0.0f) && (v <= 65535.0f) && (v == truncf(v));
+}
+
 __global__ __launch_bounds__(256) void k_row_max(const float *__restrict__ cov, const int64_t *__restrict__ goff,
                                                  const int32_t *__restrict__ glen, float *__restrict__ rowmax,
                                                  int32_t *__restrict__ x16, int n, int p)
@@ -112,11 +121,25 @@ __global__ __launch_bounds__(256) void k_row_max(const float *__restrict__ cov, 
         for (int i = w; i < p; i += 4) {
             const float *row = cov + goff[g] + (size_t) i * L;
             float m = row[0];
-            for (int j = lane; j < L; j += 64) {
-                const float v = row[j];
-                m = fmaxf(m, v);
-                ok = ok && (v >= 0.0f) && (v <= 65535.0f) && (v == truncf(v));
+            const int head = (int) (((16u - (unsigned) ((size_t) row & 15u)) & 15u) >> 2);     // floats up to the next 16-byte boundary
+            const int h = head < L ? head : L;
+            if (lane < h) row_max_acc(row[lane], m, ok);
+            const float4 *q = reinterpret_cast<const float4 *>(row + h);
+            const int n4 = (L - h) >> 2;
+            int j = lane;
+            for (; j + 192 < n4; j += 256) {               // four independent 16-byte loads per lane in flight
+                const float4 a = q[j], b = q[j + 64], c = q[j + 128], d = q[j + 192];
+                row_max_acc(a.x, m, ok); row_max_acc(a.y, m, ok); row_max_acc(a.z, m, ok); row_max_acc(a.w, m, ok);
+                row_max_acc(b.x, m, ok); row_max_acc(b.y, m, ok); row_max_acc(b.z, m, ok); row_max_acc(b.w, m, ok);
+                row_max_acc(c.x, m, ok); row_max_acc(c.y, m, ok); row_max_acc(c.z, m, ok); row_max_acc(c.w, m, ok);
+                row_max_acc(d.x, m, ok); row_max_acc(d.y, m, ok); row_max_acc(d.z, m, ok); row_max_acc(d.w, m, ok);
             }
+            for (; j < n4; j += 64) {
+                const float4 a = q[j];
+                row_max_acc(a.x, m, ok); row_max_acc(a.y, m, ok); row_max_acc(a.z, m, ok); row_max_acc(a.w, m, ok);
+            }
+            const int t0 = h + 4 * n4;                     // scalar tail (< 4 floats)
+            if (t0 + lane < L) row_max_acc(row[t0 + lane], m, ok);
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
             if (lane == 0) rowmax[(size_t) g * p + i] = m;
@@ -372,6 +395,7 @@ struct dn_handle_s {
     float last_ms = 0.f;
     float last_span_ms = 0.f;     // first launch to last end of the class kernels of the most recent dn_baseline_iteration
     float last_init_ms = 0.f;     // device time of the most recent dn_ratio_svd_sums kernel
+    float last_rowmax_ms = 0.f;   // device time of k_row_max at the most recent upload
     char init_name[64] = {0};
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr;
     // the collective inside the library (dn_comm_*): one RCCL communicator per handle, all-reduces on the handle's stream
@@ -711,10 +735,13 @@ static int finish_upload_impl(dn_handle h, const CoverageSource &src)
     HIP_TRY(hipMemcpyAsync(h->d_svoff, h->svoff.data(), sizeof(int64_t) * (size_t) (n + 1), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_tile_gene, tg.data(), sizeof(int32_t) * tg.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_tile_col, tc.data(), sizeof(int32_t) * tc.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_i0, h->stream));
     hipLaunchKernelGGL(k_row_max, dim3((unsigned) std::min<int64_t>(n, (int64_t) h->n_cus * 8)), dim3(256), 0, h->stream,
                        h->d_cov, h->d_goff, h->d_glen, h->d_rowmax, h->d_x16, (int) n, (int) p);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_i1, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    (void) hipEventElapsedTime(&h->last_rowmax_ms, h->ev_i0, h->ev_i1);
 
     // gene classes
     {
@@ -1443,6 +1470,7 @@ int dn_fetch_estimates_subset(dn_handle h, int64_t n_sel, const int64_t *gene_id
 double dn_last_kernel_ms(dn_handle h) { return h ? (double) h->last_ms : 0.0; }
 double dn_last_init_ms(dn_handle h) { return h ? (double) h->last_init_ms : 0.0; }
 double dn_last_span_ms(dn_handle h) { return h ? (double) h->last_span_ms : 0.0; }
+double dn_last_rowmax_ms(dn_handle h) { return h ? (double) h->last_rowmax_ms : 0.0; }
 const char *dn_init_kernel_name(dn_handle h) { return h ? h->init_name : ""; }
 const char *dn_main_kernel_name(dn_handle h) { return (h && h->ks) ? h->ks->baseline_name : ""; }
 double dn_class_kernel_ms(dn_handle h, int cls) { return (h && cls >= 0 && cls < dn_handle_s::NCLS) ? (double) h->cls[cls].last_ms : 0.0; }
@@ -1463,6 +1491,44 @@ int dn_synchronize(dn_handle h)
 __global__ __launch_bounds__(256) void k_copy4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4)
 {
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t) gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// read-only stream: every lane keeps four 16-byte loads in flight and folds them into one number (nothing is written but a
+// few partial sums): the ceiling a streaming READ kernel can reach on this device ("measured stream-read ceiling")
+__global__ __launch_bounds__(256) void k_read4(const float4 *__restrict__ src, float *__restrict__ sink, size_t n4)
+{
+    float acc = 0.f;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+    }
+    for (; i < n4; i += stride) { const float4 a = src[i]; acc += a.x + a.y + a.z + a.w; }
+    if (acc == 12345.678f) sink[0] = acc;                  // never true for the memset pattern: keeps the loads alive
+}
+
+extern "C" double dn_measure_read_gbps(dn_handle h, int64_t bytes, int reps)
+{
+    if (!h || bytes < (1 << 20)) return 0.0;
+    if (hipSetDevice(h->device) != hipSuccess) return 0.0;
+    float4 *a = nullptr; float *sink = nullptr;
+    const size_t n4 = (size_t) bytes / sizeof(float4);
+    if (hipMalloc(&a, n4 * sizeof(float4)) != hipSuccess) return 0.0;
+    if (hipMalloc(&sink, 256) != hipSuccess) { (void) hipFree(a); return 0.0; }
+    (void) hipMemsetAsync(a, 1, n4 * sizeof(float4), h->stream);
+    double best = 0.0;
+    for (int r = 0; r < reps + 1; r++) {
+        (void) hipEventRecord(h->ev0, h->stream);
+        hipLaunchKernelGGL(k_read4, dim3(h->n_cus * 8), dim3(256), 0, h->stream, a, sink, n4);
+        (void) hipEventRecord(h->ev1, h->stream);
+        (void) hipStreamSynchronize(h->stream);
+        float ms = 0.f;
+        (void) hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        if (r > 0 && ms > 0.f) best = std::max(best, (double) n4 * sizeof(float4) / (ms * 1e-3) / 1e9);
+    }
+    (void) hipFree(a); (void) hipFree(sink);
+    return best;
 }
 
 extern "C" double dn_measure_copy_gbps(dn_handle h, int64_t bytes, int reps)

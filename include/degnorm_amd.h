@@ -197,6 +197,8 @@ double dn_last_kernel_ms(dn_handle h);
 const char *dn_main_kernel_name(dn_handle h);
 /* The same for the most recent dn_ratio_svd_sums (the initial pass over the whole transcripts).       */
 double dn_last_init_ms(dn_handle h);
+/* Device time in ms of the row-maxima kernel of the most recent upload (one read of the whole packed coverage).          */
+double dn_last_rowmax_ms(dn_handle h);
 const char *dn_init_kernel_name(dn_handle h);
 /* Genes are run in up to three classes: class 0 = genes longer than dn_split_length() (256-thread workgroups, one per CU),
  * class 1 = the others (128-thread workgroups, two per CU), class 2 = genes of at most dn_tiny_length() bases (one wavefront
@@ -211,6 +213,10 @@ const char *dn_class_kernel_name(dn_handle h, int cls);
 int  dn_synchronize(dn_handle h);
 /* Stream-copy ceiling of this device (GB/s, float4 copy of `bytes` bytes, best of `reps`).          */
 double dn_measure_copy_gbps(dn_handle h, int64_t bytes, int reps);
+/* Stream-READ ceiling of this device (GB/s: `bytes` bytes read with four 16-byte loads per lane in flight and folded into
+ * one number, best of `reps`): what a read-only streaming kernel -- the row maxima, the two passes of the initial DI pass --
+ * is measured against, beside the 8 TB/s of the data sheet.                                              */
+double dn_measure_read_gbps(dn_handle h, int64_t bytes, int reps);
 
 #ifdef __cplusplus
 }
