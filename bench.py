@@ -440,6 +440,54 @@ def end_to_end(packed, lengths, p, reads, iters, nmf_iter, rate, device, reps=2)
                     'repeats it, `upload_s` is not separable)'.format(reps)}
 
 
+def end_to_end_sharded(ctx, cfg, p, n_genes, args, rate):
+    """
+    The sharded API end to end (--sharded-api, N > 1): run_gene_nmfoa_mpi(comm, cov_dict, reads) as degnorm_mpi calls it
+    (__main_mpi__.py:429-436) -- rank 0 holds the float64 coverage dict of the WHOLE configuration, ships every rank its packed
+    share (raw float32 buffers, point to point), every rank runs its resident shard, rank 0 collects estimates / DI / adjusted
+    counts / flags (raw buffers, to rank 0 only).  Per rank: the stage times, the bytes that rank sent and received, and its peak
+    resident set -- no rank but 0 ever holds more than its own share.  Collective: every rank calls it.
+    """
+    import resource
+    from collections import OrderedDict
+    from degnorm_amd import synth
+    from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi
+    comm, rank, world = ctx['comm'], ctx['rank'], ctx['world']
+    cov_dat, reads, in_bytes = None, None, 0
+    if rank == 0:
+        packed, lengths, reads, _ = synth.synth_packed(cfg['seed'], range(n_genes), p, cfg['l_min'], cfg['l_max'],
+                                                       n_threads=max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
+        cov_dat, o = OrderedDict(), 0
+        for g, L in enumerate(lengths):
+            L = int(L)
+            cov_dat['gene_%06d' % g] = packed[o:o + p * L].reshape(p, L).astype(np.float64)      # what the CLI hands over
+            o += p * L
+        in_bytes = int(8 * p * int(np.sum(lengths)))
+        del packed
+    sent0, recv0 = getattr(comm, 'bytes_sent', 0), getattr(comm, 'bytes_received', 0)
+    tm = {}
+    comm.Barrier()
+    t0 = time.time()
+    res = run_gene_nmfoa_mpi(comm, cov_dat, reads, degnorm_iter=args.iters, nmf_iter=args.nmf_iter, downsample_rate=rate,
+                             device=ctx['local_rank'], timings=tm)
+    total = time.time() - t0
+    mine = dict(tm, rank=rank, total_s=total, bytes_sent=int(getattr(comm, 'bytes_sent', 0) - sent0),
+                bytes_received=int(getattr(comm, 'bytes_received', 0) - recv0),
+                peak_rss_mb=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0)
+    per_rank = comm.gather_objects(mine)
+    if rank != 0:
+        return None
+    n_est = len(res['estimates'])
+    del res, cov_dat
+    return {'total_s': max(r['total_s'] for r in per_rank), 'genes_per_s_with_estimates': n_genes / max(r['total_s'] for r in per_rank),
+            'input_bytes_float64': in_bytes, 'estimates_returned': n_est, 'per_rank': per_rank,
+            'what': 'run_gene_nmfoa_mpi(comm, OrderedDict of float64 p x L matrices on rank 0, reads): scatter_s = checks + partition + '
+                    'float32 packing + shipping the shares (rank 0) / waiting for and receiving the own share (workers); upload_s = H2D of '
+                    'the share; run_s = initial pass + outer iterations + estimates of the last iteration + D2H; gather_s = results to rank 0 '
+                    '(estimates float64, DI, adjusted counts, flags), raw buffers point to point; peak_rss_mb includes what the rank held '
+                    'before the call (the bench shard, on rank 0 the float64 input dict)'}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # one configuration on this rank
 # ---------------------------------------------------------------------------------------------------------------------
@@ -537,6 +585,9 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
     else:
         counts = [(len(my_genes), int(wide.sum()), int((~wide & ~pair).sum()), int(pair.sum()), float(np.sum(lengths)))]
     if rank != 0:
+        if world > 1 and args.sharded_api:
+            eng.dev.close()                                             # the API run opens its own handles
+            end_to_end_sharded(ctx, cfg, p, n_genes, args, rate)        # collective: rank 0 joins after its post-clock checks
         return None
 
     value = n_genes * steps / dt
@@ -669,6 +720,9 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
         eng.dev.close()                                                 # free the shard before the follow-up runs open their own handles
     except Exception:
         pass
+    if world > 1 and args.sharded_api:
+        out['end_to_end_sharded'] = dict(end_to_end_sharded(ctx, cfg, p, n_genes, args, rate),
+                                         pieces_of_the_timed_path={'upload_s': t_up, 'step_s': dt / steps})
     if world == 1 and n_cpu > 0:
         out['cpu_baseline'], ref, covs, rd = cpu_baseline(cfg, config, p, args.nmf_iter, args.iters, rate, n_cpu, n_single)
         if out['parity'] is not None:
@@ -792,6 +846,9 @@ def parse(argv=None):
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the GeneNMFOA.fit() end-to-end timing (config 2, N = 1)')
     ap.add_argument('--no-also', action='store_true', help='skip the config-4 measurement appended to the default config-2 line')
     ap.add_argument('--no-rccl', action='store_true', help='N = 1 without torchrun: do not open a one-rank RCCL process group')
+    ap.add_argument('--sharded-api', action='store_true',
+                    help='N > 1: after the clock, also run the reference-signature API run_gene_nmfoa_mpi on the whole configuration '
+                         '(rank 0 holds the float64 dict) and report scatter / run / gather per rank (`end_to_end_sharded`)')
     ap.add_argument('--torch-collective', action='store_true',
                     help='run the per-iteration all-reduce through torch.distributed on the library\'s device buffer (round 3) instead of '
                          'inside the library (dn_comm_*, the default with the nccl backend)')

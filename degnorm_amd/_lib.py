@@ -80,6 +80,7 @@ def load(build_if_missing=False):
     lib.dn_init_kernel_name.restype = c.c_char_p
     lib.dn_split_length.argtypes = [vp]
     lib.dn_split_length.restype = i32
+    lib.dn_class_lengths.argtypes = [vp, i32, i32, P(i32), P(i32)]
     lib.dn_tiny_length.argtypes = [vp]
     lib.dn_tiny_length.restype = i32
     lib.dn_class_kernel_ms.argtypes = [vp, c.c_int]
@@ -409,6 +410,12 @@ class Device:
 
     def split_length(self):
         return int(self.lib.dn_split_length(self.h))
+
+    def class_lengths(self, p, downsample_rate=1):
+        """(split_len, tiny_len) of a cohort of p samples on this device, before any upload (0: the class does not exist)."""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(self.lib.dn_class_lengths(self.h, int(p), int(downsample_rate), ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def tiny_length(self):
         return int(self.lib.dn_tiny_length(self.h))

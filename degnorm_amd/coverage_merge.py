@@ -27,9 +27,14 @@ def gene_intervals(chrom_exon_df):
     """
     df = chrom_exon_df.sort_values('gene_end', axis=0)
     genes = df['gene'].unique().tolist()
+    # one pass over the table (round 3 filtered the DataFrame once per gene: O(genes x exons) on a real chromosome)
+    codes = {g: k for k, g in enumerate(genes)}
+    per_gene = [[] for _ in genes]
+    for g, a, b in zip(df['gene'].tolist(), (df['start'].values - 1).tolist(), df['end'].values.tolist()):
+        per_gene[codes[g]].append((a, b))
     out = []
-    for gene, sub in ((g, df[df.gene == g]) for g in genes):
-        iv = sorted(zip((sub.start.values - 1).tolist(), sub.end.values.tolist()))
+    for iv in per_gene:
+        iv.sort()
         merged = []
         for a, b in iv:
             if b <= a:

@@ -685,6 +685,57 @@ static int upload_ragged_chunks(dn_handle h, const CoverageSource &src)
     return rc == DN_OK ? DN_OK : fail(rc, msg);
 }
 
+// Class boundaries of a cohort of p samples served by kernel set `ks` (see dn_handle_s::GeneClass): genes longer than
+// split_len run one per CU (wide class), the others two per CU (narrow), those of at most tiny_len bases one wavefront each
+// (pair class; `pair` = its kernel set or null).  0 = the class does not exist.  Needs the device (occupancy queries).
+static void class_lengths(const dn::KernelSet *ks, int32_t p, int32_t &split_len, int32_t &tiny_len, const dn::KernelSet *&pair)
+{
+    {
+        const char *env = getenv("DN_SPLIT_LEN");
+        const dn::KernelSet *narrow = (ks->p != 0) ? dn::kernel_set_narrow(p) : nullptr;
+        split_len = 0;
+        if (env) split_len = atoi(env);
+        else if (narrow) {
+            // Narrow class (128-thread workgroups, two genes per CU): its fixed cost per inner iteration (reduce +
+            // eigen-solve) is paid by half a CU instead of a whole one, so it wins for every gene it can
+            // keep mostly on chip.  On-chip columns of a narrow workgroup = register tier + LDS tier (p = 10: 1 280 + 975);
+            // measured optimum of the boundary on config 2: 3 600-4 000 bases, i.e. ~1.7 x that capacity (split 2 600 /
+            // 3 000 / 3 400 / 3 800 / 4 200 -> 11 510 / 11 740 / 11 920 / 11 950 / 11 890 genes/s).  Without a register
+            // tier: ~2.1 x the LDS columns (round 1: 2 000-2 200 at 975 columns).
+            const int per_cu_n = std::max(1, narrow->blocks_per_cu(0));
+            const int64_t lds_n = (160 * 1024) / per_cu_n - (int64_t) narrow->static_lds_bytes - 256;
+            const int64_t lds_cols_n = std::max<int64_t>(0, lds_n / (8 * (int64_t) (p + (p & 1))));
+            const int64_t reg_cols_n = narrow->reg_tier_cols;
+            // round 3: 1.775 x capacity (4 000 bases at p = 10) instead of 1.7 x (3 831): the same on the full configuration (-0.2 %), but
+            // +2.4 % at the shard sizes of 2 and 8 GPUs (10 000 / 2 500 genes: 727 vs 745 ms, 191 vs 196 ms per run) -- with few genes
+            // per GPU the wide class (one gene per CU, launched first) is what quantises: 500 instead of 595 genes on 256 slots
+            split_len = (int32_t) (reg_cols_n > 0 ? (int64_t) (1.775 * (double) (reg_cols_n + lds_cols_n)) : (int64_t) (2.1 * (double) lds_cols_n));
+        }
+        if (!narrow) split_len = 0;
+        if (!env && p >= 25) split_len = 0;     // wide cohorts (MFMA Gram): one class measured 3-5 % faster than two
+        // Pair class: one wavefront per gene pays reduce + eigen-solve on ONE SIMD instead of two and needs no cross-wave step;
+        // two such genes share a workgroup of the narrow class's shape.  A wavefront keeps its register tier plus its half of
+        // the workgroup's LDS tile on chip (p = 10: 640 + ~480 columns); as for the narrow class the measured optimum of the
+        // boundary is ~1.7 x that capacity (config 2, sweep in ms at 900 / 1 120 / 1 300 / 1 500 / 1 700 / 2 000 / 2 300 /
+        // 2 600 / 3 000: 300.1 / 298.3 / 295.4 / 293.5 / 292.2 / 291.7 / 293.0 / 296.1 / 304.7; without the class 307.7).
+        // DN_TINY_LEN overrides the boundary (0: no such class).
+        pair = (ks->p != 0 && split_len > 0) ? dn::kernel_set_pair(p) : nullptr;
+        tiny_len = 0;
+        if (pair) {
+            const char *tenv = getenv("DN_TINY_LEN");
+            if (tenv) tiny_len = atoi(tenv);
+            else {
+                const int per_cu_t = std::max(1, pair->blocks_per_cu(0));
+                const int64_t lds_t = ((160 * 1024) / per_cu_t - (int64_t) pair->static_lds_bytes - 256) / std::max(1, pair->units);
+                const int64_t lds_cols_t = std::max<int64_t>(0, lds_t / (8 * (int64_t) (p + (p & 1))));
+                tiny_len = (int32_t) (1.7 * (double) (pair->reg_tier_cols + lds_cols_t));
+            }
+            tiny_len = std::min(tiny_len, split_len);
+            if (tiny_len <= 0) { pair = nullptr; tiny_len = 0; }
+        }
+    }
+}
+
 static int finish_upload_impl(dn_handle h, const CoverageSource &src)
 {
     const int64_t n = h->n;
@@ -745,54 +796,15 @@ static int finish_upload_impl(dn_handle h, const CoverageSource &src)
 
     // gene classes
     {
-        const char *env = getenv("DN_SPLIT_LEN");
-        const dn::KernelSet *narrow = (h->ks->p != 0) ? dn::kernel_set_narrow(p) : nullptr;
-        if (env) h->split_len = atoi(env);
-        else if (narrow) {
-            // Narrow class (128-thread workgroups, two genes per CU): its fixed cost per inner iteration (reduce +
-            // eigen-solve, ~3.3 k cycles) is paid by half a CU instead of a whole one, so it wins for every gene it can
-            // keep mostly on chip.  On-chip columns of a narrow workgroup = register tier + LDS tier (p = 10: 1 280 + 975);
-            // measured optimum of the boundary on config 2: 3 600-4 000 bases, i.e. ~1.7 x that capacity (split 2 600 /
-            // 3 000 / 3 400 / 3 800 / 4 200 -> 11 510 / 11 740 / 11 920 / 11 950 / 11 890 genes/s).  Without a register
-            // tier: ~2.1 x the LDS columns (round 1: 2 000-2 200 at 975 columns).
-            const int per_cu_n = std::max(1, narrow->blocks_per_cu(0));
-            const int64_t lds_n = (160 * 1024) / per_cu_n - (int64_t) narrow->static_lds_bytes - 256;
-            const int64_t lds_cols_n = std::max<int64_t>(0, lds_n / (8 * (int64_t) (p + (p & 1))));
-            const int64_t reg_cols_n = narrow->reg_tier_cols;
-            // round 3: 1.775 x capacity (4 000 bases at p = 10) instead of 1.7 x (3 831): the same on the full configuration (-0.2 %), but
-            // +2.4 % at the shard sizes of 2 and 8 GPUs (10 000 / 2 500 genes: 727 vs 745 ms, 191 vs 196 ms per run) -- with few genes
-            // per GPU the wide class (one gene per CU, launched first) is what quantises: 500 instead of 595 genes on 256 slots
-            h->split_len = (int32_t) (reg_cols_n > 0 ? (int64_t) (1.775 * (double) (reg_cols_n + lds_cols_n)) : (int64_t) (2.1 * (double) lds_cols_n));
-        }
-        if (!narrow) h->split_len = 0;
-        if (!env && p >= 25) h->split_len = 0;     // wide cohorts (MFMA Gram): one class measured 3-5 % faster than two
-        // Pair class: one wavefront per gene pays reduce + eigen-solve on ONE SIMD instead of two and needs no cross-wave step;
-        // two such genes share a workgroup of the narrow class's shape.  A wavefront keeps its register tier plus its half of
-        // the workgroup's LDS tile on chip (p = 10: 640 + ~480 columns); as for the narrow class the measured optimum of the
-        // boundary is ~1.7 x that capacity (config 2, sweep in ms at 900 / 1 120 / 1 300 / 1 500 / 1 700 / 2 000 / 2 300 /
-        // 2 600 / 3 000: 300.1 / 298.3 / 295.4 / 293.5 / 292.2 / 291.7 / 293.0 / 296.1 / 304.7; without the class 307.7).
-        // DN_TINY_LEN overrides the boundary (0: no such class).
-        const dn::KernelSet *pair = (h->ks->p != 0 && h->split_len > 0) ? dn::kernel_set_pair(p) : nullptr;
-        h->tiny_len = 0;
-        if (pair) {
-            const char *tenv = getenv("DN_TINY_LEN");
-            if (tenv) h->tiny_len = atoi(tenv);
-            else {
-                const int per_cu_t = std::max(1, pair->blocks_per_cu(0));
-                const int64_t lds_t = ((160 * 1024) / per_cu_t - (int64_t) pair->static_lds_bytes - 256) / std::max(1, pair->units);
-                const int64_t lds_cols_t = std::max<int64_t>(0, lds_t / (8 * (int64_t) (p + (p & 1))));
-                h->tiny_len = (int32_t) (1.7 * (double) (pair->reg_tier_cols + lds_cols_t));
-            }
-            h->tiny_len = std::min(h->tiny_len, h->split_len);
-            if (h->tiny_len <= 0) { pair = nullptr; h->tiny_len = 0; }
-        }
+        const dn::KernelSet *pair = nullptr;
+        class_lengths(h->ks, p, h->split_len, h->tiny_len, pair);
         std::vector<int32_t> ord[dn_handle_s::NCLS];
         for (int32_t g : order) {                                                                           // stays longest-first
             const int32_t L = h->glen[g];
             ord[(h->split_len > 0 && L <= h->split_len) ? ((pair && L <= h->tiny_len) ? 2 : 1) : 0].push_back(g);
         }
         h->cls[0].ks = h->ks;
-        h->cls[1].ks = narrow;
+        h->cls[1].ks = (h->ks->p != 0 && h->split_len > 0) ? dn::kernel_set_narrow(p) : nullptr;
         h->cls[2].ks = pair;
         {
             // Queue order of a class: longest first, then zigzagged (longest, shortest, 2nd longest, 2nd shortest, ...).
@@ -1476,6 +1488,18 @@ const char *dn_main_kernel_name(dn_handle h) { return (h && h->ks) ? h->ks->base
 double dn_class_kernel_ms(dn_handle h, int cls) { return (h && cls >= 0 && cls < dn_handle_s::NCLS) ? (double) h->cls[cls].last_ms : 0.0; }
 const char *dn_class_kernel_name(dn_handle h, int cls) { return (h && cls >= 0 && cls < dn_handle_s::NCLS && h->cls[cls].ks && h->cls[cls].n > 0) ? h->cls[cls].ks->baseline_name : ""; }
 int32_t dn_tiny_length(dn_handle h) { return h ? h->tiny_len : 0; }
+int dn_class_lengths(dn_handle h, int32_t p, int32_t downsample_rate, int32_t *split_len, int32_t *tiny_len)
+{
+    if (!h || !split_len || !tiny_len) return fail(DN_E_INVALID, "dn_class_lengths: null argument");
+    const dn::KernelSet *ks = dn::kernel_set_for(p);
+    if (!ks) return fail(DN_E_UNSUPPORTED, "no kernels compiled for p = " + std::to_string(p));
+    HIP_TRY(hipSetDevice(h->device));
+    *split_len = 0; *tiny_len = 0;
+    if (downsample_rate > 1 && p >= 8) return DN_OK;        // the one-wavefront-per-gene family of the down-sampled regime has one class
+    const dn::KernelSet *pair = nullptr;
+    class_lengths(ks, p, *split_len, *tiny_len, pair);
+    return DN_OK;
+}
 int32_t dn_split_length(dn_handle h) { return h ? h->split_len : 0; }
 int dn_synchronize(dn_handle h)
 {

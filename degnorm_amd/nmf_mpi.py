@@ -113,6 +113,39 @@ class TorchComm(object):
         self.dist.broadcast_object_list(box, src=root, group=self.group)
         return box[0]
 
+    # raw buffers, point to point: coverage shares and results travel as bytes (chunked dist.send / dist.recv on uint8 views --
+    # gloo: straight from / into the numpy memory; nccl: staged through the device, RCCL p2p over xGMI), never as pickles
+    CHUNK_BYTES = 1 << 28
+    bytes_sent = 0
+    bytes_received = 0
+
+    def send_array(self, arr, dest):
+        a = np.ascontiguousarray(arr)
+        flat = a.reshape(-1).view(np.uint8)
+        for lo in range(0, flat.size, self.CHUNK_BYTES):
+            piece = flat[lo:lo + self.CHUNK_BYTES]
+            if not piece.flags.writeable:                             # a memory-mapped side-car: torch wants a writable buffer
+                piece = np.array(piece)
+            t = self.torch.from_numpy(piece)
+            if self.backend == 'nccl':
+                t = t.to(self.device)
+            self.dist.send(t, dst=dest, group=self.group)
+        self.bytes_sent += int(flat.size)
+
+    def recv_array(self, shape, dtype, source):
+        out = np.empty(shape, dtype=dtype)
+        flat = out.reshape(-1).view(np.uint8)
+        for lo in range(0, flat.size, self.CHUNK_BYTES):
+            piece = flat[lo:lo + self.CHUNK_BYTES]
+            if self.backend == 'nccl':
+                t = self.torch.empty(piece.size, dtype=self.torch.uint8, device=self.device)
+                self.dist.recv(t, src=source, group=self.group)
+                piece[...] = t.cpu().numpy()
+            else:
+                self.dist.recv(self.torch.from_numpy(piece), src=source, group=self.group)
+        self.bytes_received += int(flat.size)
+        return out
+
     # point-to-point object passing, for callers that drive this like an mpi4py communicator
     def send(self, obj, dest, tag=0):
         self.dist.send_object_list([obj], dst=dest, group=self.group)
@@ -157,6 +190,24 @@ def _bcast(comm, obj):
             comm.send(obj, dest=r, tag=555 + r)
         return obj
     return comm.recv(source=0, tag=555 + comm.rank)
+
+
+def _send_arrays(comm, dest, tag, arrays):
+    """numpy arrays to one rank: as raw buffers when the communicator can (TorchComm.send_array), else as one object (the
+    reference's own way: mpi4py pickles, nmf_mpi.py:627)."""
+    if hasattr(comm, 'send_array'):
+        for a in arrays:
+            comm.send_array(a, dest)
+    else:
+        comm.send(tuple(np.ascontiguousarray(a) for a in arrays), dest=dest, tag=tag)
+
+
+def _recv_arrays(comm, source, tag, specs):
+    """The receiving side of _send_arrays: specs = [(shape, dtype), ...] (the receiver knows them from the partition)."""
+    if hasattr(comm, 'recv_array'):
+        return [comm.recv_array(shape, dtype, source) for shape, dtype in specs]
+    got = comm.recv(source=source, tag=tag)
+    return [np.asarray(a, dtype=dt).reshape(shape) for a, (shape, dt) in zip(got, specs)]
 
 
 def _gather(comm, obj):
@@ -519,24 +570,118 @@ def _pack_f32(mats):
     return packed, lengths, inexact
 
 
+def _class_lengths(device, p, downsample_rate):
+    """(split_len, tiny_len) of a p-sample cohort on this rank's GPU, or None when the device cannot say (test stand-ins)."""
+    try:
+        dev = _lib.Device(int(os.environ.get('LOCAL_RANK', 0)) if device is None else int(device))
+    except Exception:
+        return None
+    try:
+        return dev.class_lengths(p, downsample_rate) if hasattr(dev, 'class_lengths') else None
+    finally:
+        dev.close()
+
+
+def _partition(li_vec, size, p, downsample_rate, partition, device):
+    if partition == 'contiguous':
+        parts = split_into_chunks(list(range(len(li_vec))), size)      # nmf_mpi.py:605
+    elif partition == 'balanced':
+        parts = partition_by_cost(li_vec, size, p=p, downsample_rate=abs(int(downsample_rate)),
+                                  class_lengths=_class_lengths(device, p, abs(int(downsample_rate))))
+    else:
+        raise ValueError("partition must be 'balanced' or 'contiguous'")
+    parts = [list(q) for q in parts]
+    while len(parts) < size:                                            # fewer chunks than ranks: idle ranks get nothing
+        parts.append([])
+    return parts
+
+
+def _run_shard_and_gather(comm, eng_kw, my_names, packed, lengths, my_x, my_ids, n_genes, p, degnorm_iter,
+                          all_genes, li_vec, parts, want_estimates=True, timings=None):
+    """
+    Every rank: its resident shard through the engine; then rank 0 collects -- and ONLY rank 0: raw buffers point to point, in
+    rank order (nmf_mpi.py:796-815 gathers the same things as pickled tuples), rows scattered back into the original gene order.
+    `all_genes`, `li_vec`, `parts` are needed on rank 0 only (the receiver knows every shape from them).
+    """
+    import time
+    size, rank = comm.size, comm.rank
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
+    eng = ShardedNMFOA(comm=comm, **eng_kw)
+    eng.gene_names = my_names
+    eng.load_packed(packed, lengths, p, my_x, global_ids=my_ids, n_total=n_genes)
+    del packed
+    tm['upload_s'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    flat, lens = eng.run(want_estimates=want_estimates, flat=True) if want_estimates else (eng.run(want_estimates=False), None)
+    if not want_estimates:
+        flat = np.zeros(0)
+    tm['run_s'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    logging.info('({0}/{1}) -- finished {2} genes'.format(rank + 1, size, eng.n_local))
+    n_it = abs(int(degnorm_iter))
+    mine = (flat, np.ascontiguousarray(eng.rho, dtype=np.float64).reshape(eng.n_local, p),
+            np.ascontiguousarray(eng.x_adj, dtype=np.float64).reshape(eng.n_local, p),
+            np.ascontiguousarray(eng.ran_baseline_selection, dtype=np.uint8).reshape(eng.n_local, n_it))
+    if rank != 0:
+        _send_arrays(comm, 0, 666 + rank, mine)
+        comm.Barrier()
+        tm['gather_s'] = time.perf_counter() - t0
+        return None
+    li_vec = np.asarray(li_vec, dtype=np.int64)
+    rho, x_adj = np.empty((n_genes, p)), np.empty((n_genes, p))
+    ran = np.empty((n_genes, n_it), dtype=bool)
+    flats = [None] * size
+    for r in range(size):
+        idx = np.asarray(parts[r], dtype=np.int64)
+        if r == 0:
+            got = mine
+        else:
+            n_r = len(idx)
+            n_est = int(p * li_vec[idx].sum()) if want_estimates else 0
+            got = _recv_arrays(comm, r, 666 + r, [((n_est,), np.float64), ((n_r, p), np.float64), ((n_r, p), np.float64), ((n_r, n_it), np.uint8)])
+        flats[r] = got[0]
+        if len(idx):
+            rho[idx], x_adj[idx], ran[idx] = got[1], got[2], got[3].astype(bool)
+    comm.Barrier()
+    tm['gather_s'] = time.perf_counter() - t0
+    estimates = None
+    if want_estimates:
+        by_pos = [None] * n_genes
+        for r in range(size):
+            o = 0
+            for k in parts[r]:
+                L = int(li_vec[k])
+                by_pos[k] = flats[r][o:o + p * L].reshape(p, L)         # views of the rank's buffer: no further copy
+                o += p * L
+        estimates = OrderedDict((g, by_pos[k]) for k, g in enumerate(all_genes))      # original gene order (nmf_mpi.py:852-860)
+    return {'estimates': estimates, 'rho': rho, 'x_adj': x_adj, 'ran_baseline_selection': ran}
+
+
 def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate=1, min_high_coverage=50,
                        nmf_iter=100, bins=20, n_jobs=1, skip_baseline_selection=False, random_state=123,
-                       device=None, partition='balanced'):
+                       device=None, partition='balanced', want_estimates=True, timings=None):
     """
     Gene-sharded DegNorm run with the reference's signature (nmf_mpi.py:555-580).  Rank 0 holds
     ``cov_dat`` (OrderedDict gene -> p x L) and ``reads_dat`` (n x p) and ships each worker its share once
-    (nmf_mpi.py:603-629) -- as ONE packed float32 buffer per worker (the layout the device consumes: half the bytes of
-    the reference's float64 pickles and no per-gene objects); every rank then keeps its genes on its own GPU.
+    (nmf_mpi.py:603-629) -- as ONE packed float32 buffer per worker plus three small arrays, sent as raw bytes (the layout the
+    device consumes: half the bytes of the reference's float64 pickles, no per-gene objects, no pickling of the data); every rank
+    then keeps its genes on its own GPU.  Results come back to rank 0 only, as raw buffers (round 3 all-gathered pickles: every
+    rank received every rank's estimates).
     ``partition`` (extra): 'balanced' deals the genes by predicted cost so that every GPU gets the same share of every gene
-    class (utils.partition_by_cost), 'contiguous' is the reference's equal-count chunking (nmf_mpi.py:605); per-gene
-    results do not depend on it (the down-sampling offsets are drawn per global gene id), rows come back in the
-    original order.  Input errors found on rank 0 are raised on EVERY rank (nobody is left waiting in a receive), and
-    a rank without genes (fewer chunks than ranks, nmf_mpi.py:613) takes part in the collectives with zeros.
+    class (utils.partition_by_cost with the class boundaries of THIS sample count on the device, dn_class_lengths),
+    'contiguous' is the reference's equal-count chunking (nmf_mpi.py:605); per-gene results do not depend on it (the
+    down-sampling offsets are drawn per global gene id), rows come back in the original order.  ``want_estimates`` (extra):
+    False leaves the p x L estimates on the GPUs ('estimates': None) for callers that only need the DI scores.
+    Input errors found on rank 0 are raised on EVERY rank (nobody is left waiting in a receive), and a rank without genes
+    (fewer chunks than ranks, nmf_mpi.py:613) takes part in the collectives with zeros.
     Returns, on rank 0, {'estimates': {gene: p x L}, 'rho', 'x_adj', 'ran_baseline_selection'} in the
     original gene order (nmf_mpi.py:852-860), None elsewhere.
     """
+    import time
     size, rank = comm.size, comm.rank
-    err, parts, n_genes, p = None, None, 0, 0
+    t_start = time.perf_counter()
+    err, parts, n_genes, p, all_genes, li_vec = None, None, 0, 0, None, None
     if rank == 0:
         try:
             all_genes = list(cov_dat.keys())
@@ -556,14 +701,7 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
                 raise ValueError('read count matrix must be (number of genes) x (number of samples)')
             if abs(int(downsample_rate)) > 1 and not np.min(li_vec) >= abs(int(downsample_rate)):
                 raise ValueError('downsample_rate is too large; take-every size > at least one gene.')
-            if partition == 'contiguous':
-                parts = split_into_chunks(list(range(n_genes)), size)    # nmf_mpi.py:605
-            elif partition == 'balanced':
-                parts = partition_by_cost(li_vec, size, p=p, downsample_rate=abs(int(downsample_rate)))
-            else:
-                raise ValueError("partition must be 'balanced' or 'contiguous'")
-            while len(parts) < size:                                      # fewer chunks than ranks: idle ranks get nothing
-                parts.append([])
+            parts = _partition(li_vec, size, p, downsample_rate, partition, device)
         except Exception as e:                                            # ANY failure of the checks reaches every rank: nobody waits in a receive
             err = str(e) if isinstance(e, ValueError) else '{0}: {1}'.format(type(e).__name__, e)
     err, n_genes, p = _bcast(comm, (err, n_genes, p))
@@ -577,40 +715,22 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
             packed, lengths, bad = _pack_f32([cov_dat[all_genes[k]] for k in idx])
             n_inexact += bad
             if r > 0:
-                comm.send(([all_genes[k] for k in idx], packed, lengths, x[idx], np.asarray(idx, dtype=np.int64)), dest=r, tag=333 + r)
+                comm.send(([all_genes[k] for k in idx], int(packed.size)), dest=r, tag=333 + r)      # names + sizes: the only pickle
+                _send_arrays(comm, r, 444 + r, (packed, lengths, x[idx], np.asarray(idx, dtype=np.int64)))
         if n_inexact:
             logging.warning('{0} coverage values are not exactly representable in float32; they were rounded on upload.'.format(n_inexact))
         my_names, my_x, my_ids = [all_genes[k] for k in parts[0]], x[parts[0]], np.asarray(parts[0], dtype=np.int64)
     else:
-        my_names, packed, lengths, my_x, my_ids = comm.recv(source=0, tag=333 + rank)
-
-    eng = ShardedNMFOA(comm=comm, device=device, degnorm_iter=degnorm_iter, downsample_rate=downsample_rate,
-                       min_high_coverage=min_high_coverage, nmf_iter=nmf_iter, bins=bins,
-                       skip_baseline_selection=skip_baseline_selection, random_state=random_state)
-    eng.load_packed(packed, lengths, p, my_x, global_ids=my_ids, n_total=n_genes)
-    del packed
-    flat, lens = eng.run(want_estimates=True, flat=True)
-    logging.info('({0}/{1}) -- finished {2} genes'.format(rank + 1, size, eng.n_local))
-
-    pieces = _gather(comm, (my_names, flat, lens, eng.rho, eng.x_adj, eng.ran_baseline_selection))
-    comm.Barrier()
-    if rank != 0:
-        return None
-    by_name = dict()
-    for genes_r, flat_r, lens_r, _, _, _ in pieces:
-        o = 0
-        for g, L in zip(genes_r, lens_r):
-            by_name[g] = flat_r[o:o + p * int(L)].reshape(p, int(L))
-            o += p * int(L)
-    estimates = OrderedDict((g, by_name[g]) for g in all_genes)       # original gene order (nmf_mpi.py:852-860)
-
-    def rows(k, dtype, width):
-        out = np.empty((n_genes, width), dtype=dtype)
-        for r, pc in enumerate(pieces):
-            out[parts[r]] = pc[k]
-        return out
-    return {'estimates': estimates, 'rho': rows(3, np.float64, p), 'x_adj': rows(4, np.float64, p),
-            'ran_baseline_selection': rows(5, bool, abs(int(degnorm_iter)))}
+        my_names, n_val = comm.recv(source=0, tag=333 + rank)
+        n_r = len(my_names)
+        packed, lengths, my_x, my_ids = _recv_arrays(comm, 0, 444 + rank, [((n_val,), np.float32), ((n_r,), np.int64),
+                                                                           ((n_r, p), np.float64), ((n_r,), np.int64)])
+    if timings is not None:
+        timings['scatter_s'] = time.perf_counter() - t_start              # checks, partition, packing, shipping the shares
+    eng_kw = dict(device=device, degnorm_iter=degnorm_iter, downsample_rate=downsample_rate, min_high_coverage=min_high_coverage,
+                  nmf_iter=nmf_iter, bins=bins, skip_baseline_selection=skip_baseline_selection, random_state=random_state)
+    return _run_shard_and_gather(comm, eng_kw, my_names, packed, lengths, my_x, my_ids, n_genes, p, degnorm_iter,
+                                 all_genes, li_vec, parts, want_estimates=want_estimates, timings=timings)
 
 
 def save_results(genes_df, estimates, rho, x_adj, ran_baseline_selection, sample_ids=None, output_dir='.'):

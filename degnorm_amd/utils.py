@@ -27,35 +27,58 @@ def partition_by_length(lengths, n):
     return [sorted(q) for q in parts]
 
 
-def predicted_gene_cost(lengths, p=10, downsample_rate=1):
+P10_CLASS_LENGTHS = (4000, 1888)      # (split_len, tiny_len) of a p = 10 cohort on MI355X (dn_class_lengths): only a default for callers without a device
+
+
+def gene_classes(lengths, split_len, tiny_len):
+    """Class of every gene as the device will run it: 0 wide (longer than split_len), 1 narrow, 2 pair (at most tiny_len bases);
+    split_len = 0: one class (include/degnorm_amd.h dn_class_lengths)."""
+    L = np.asarray(lengths, dtype=np.int64)
+    if not split_len or split_len <= 0:
+        return np.zeros(len(L), dtype=np.int64)
+    return np.where(L > split_len, 0, np.where((tiny_len or 0) > 0, np.where(L > tiny_len, 1, 2), 1))
+
+
+def predicted_gene_cost(lengths, p=10, downsample_rate=1, class_lengths=None):
     """
     Relative cost of one outer iteration of a gene, from its length alone (known before anything is uploaded): the number of
     active columns (L, or ceil(L / rate) when down-sampling) plus the fixed part every inner iteration pays (reduction +
     eigen-solve), expressed in columns -- the constants are the measured per-column / per-iteration cycle counts of the
-    class the gene will run in (~700-1 200 cycles per column per lane of 64-256 lanes, ~5 800 per inner
-    iteration).  Only ratios matter.  Genes of the down-sampled regime cost the same fixed part each.
+    class the gene will run in.  Only ratios matter.  Genes of the down-sampled regime cost the same fixed
+    part each.  `class_lengths` = (split_len, tiny_len) of THIS cohort on the device (Device.class_lengths(p): the boundaries
+    depend on p -- register and LDS capacity per column); without them p = 10 gets its known boundaries and any other sample
+    count is treated as one class.
     """
     L = np.asarray(lengths, dtype=np.float64)
     if downsample_rate > 1:
         return np.ceil(L / float(downsample_rate)) + 64.0
-    lanes = np.where(L > 4000, 256.0, np.where(L > 1888, 128.0, 64.0))       # wide / narrow / pair class (p = 10 boundaries)
-    per_col = np.where(L > 4000, 1.25, 1.0)                                  # the wide class spills: ~25 % more per column
-    # columns per lane x cost per column + fixed part worth ~6 columns per lane, times the SIMDs the gene occupies
-    return (L / lanes * per_col + 6.0) * (lanes / 64.0)
+    if class_lengths is None:
+        class_lengths = P10_CLASS_LENGTHS if int(p) == 10 else (0, 0)
+    cls = gene_classes(L, class_lengths[0], class_lengths[1])
+    if not class_lengths[0]:
+        return L / 256.0 + 4.0                                               # one class: columns per lane + the fixed part
+    lanes = np.where(cls == 0, 256.0, np.where(cls == 1, 128.0, 64.0))        # wide / narrow / pair class
+    per_col = np.where(cls == 0, 1.25, 1.0)                                   # the wide class spills: ~25 % more per column
+    # columns per lane x cost per column + fixed part worth ~4 columns per lane (round 4: the vector-pipe eigen-solve; 6 before),
+    # times the SIMDs the gene occupies
+    return (L / lanes * per_col + 4.0) * (lanes / 64.0)
 
 
-def partition_by_cost(lengths, n, p=10, downsample_rate=1):
+def partition_by_cost(lengths, n, p=10, downsample_rate=1, class_lengths=None):
     """
     Gene partition for the sharded run balanced on PREDICTED COST (predicted_gene_cost) instead of on length: genes are
     taken most expensive first and each goes to the part with the least cost so far (LPT), ties to the part with fewer genes
     of the gene's class, so that every GPU also gets the same share of every gene class (each class is its own kernel and
-    queue on a GPU).  Inside a part the original gene order is kept; always returns n lists.  Per-gene results do not depend
-    on the partition; the reference shards contiguous equal-count chunks (nmf_mpi.py:605).
+    queue on a GPU; `class_lengths`: see predicted_gene_cost).  Inside a part the original gene order is kept; always returns n
+    lists.  Per-gene results do not depend on the partition; the reference shards contiguous equal-count chunks
+    (nmf_mpi.py:605).
     """
     n = int(n)
     L = np.asarray(lengths, dtype=np.int64)
-    cost = predicted_gene_cost(L, p, downsample_rate)
-    cls = np.where(L > 4000, 0, np.where(L > 1888, 1, 2))
+    if class_lengths is None:
+        class_lengths = P10_CLASS_LENGTHS if int(p) == 10 else (0, 0)
+    cost = predicted_gene_cost(L, p, downsample_rate, class_lengths)
+    cls = gene_classes(L, class_lengths[0], class_lengths[1]) if downsample_rate <= 1 else np.zeros(len(L), dtype=np.int64)
     order = np.lexsort((np.arange(len(L)), -cost))                           # most expensive first, stable
     parts = [[] for _ in range(n)]
     load = np.zeros(n)
@@ -69,6 +92,22 @@ def partition_by_cost(lengths, n, p=10, downsample_rate=1):
         parts[r].append(int(g))
         load[r] += cost[g]
         ncls[r, c] += 1
+    return [sorted(q) for q in parts]
+
+
+def partition_by_measured_cost(cost, n):
+    """
+    LPT on MEASURED per-gene costs (the cycle counters of an outer iteration, trace column 7 ... see ShardedNMFOA.redeal): most
+    expensive gene first onto the least loaded part.  Returns n sorted lists of gene positions.
+    """
+    cost = np.asarray(cost, dtype=np.float64)
+    order = np.lexsort((np.arange(len(cost)), -cost))
+    parts = [[] for _ in range(int(n))]
+    load = np.zeros(int(n))
+    for g in order:
+        r = int(np.argmin(load))
+        parts[r].append(int(g))
+        load[r] += cost[g]
     return [sorted(q) for q in parts]
 
 

@@ -54,16 +54,18 @@ def write_sidecars(degnorm_dir, chroms=None):
         p = int(cov_dat[genes[0]].shape[0]) if genes else 0
         packed = np.lib.format.open_memmap(npy_file, mode='w+', dtype=np.float32, shape=(int(p * lengths.sum()),))
         o, inexact = 0, 0
-        for g, L in zip(genes, lengths):
+        maxcov = np.zeros(len(genes))
+        for k, (g, L) in enumerate(zip(genes, lengths)):
             m = np.asarray(cov_dat[g])
             blk = packed[o:o + p * int(L)].reshape(p, int(L))
             blk[...] = m
             inexact += int(np.count_nonzero(blk != m))
+            maxcov[k] = float(m.max())                     # what the CLI's gene filter asks of a gene (__main__.py:229): no need to read it again
             o += p * int(L)
         packed.flush()
         del packed
         st = os.stat(pkl_file)
-        np.savez(idx_file, genes=np.array(genes, dtype=str), lengths=lengths, p=p, inexact=inexact,
+        np.savez(idx_file, genes=np.array(genes, dtype=str), lengths=lengths, p=p, inexact=inexact, maxcov=maxcov,
                  pkl_size=st.st_size, pkl_mtime_ns=st.st_mtime_ns)
         out[chrom] = inexact
     return out
@@ -100,6 +102,81 @@ def _read_sidecar(pkl_file, npy_file, idx_file):
         out[g] = packed[o:o + p * L].reshape(p, L)
         o += p * L
     return out
+
+
+def _sidecar_index(degnorm_dir, chrom):
+    """
+    The side-car's index alone (gene names, lengths, per-gene maximum, p) when the side-car can be trusted -- made from the pickle
+    that is there now, describing the data file that is there now, written with the per-gene maxima -- else None.  No coverage is read.
+    """
+    pkl_file, npy_file, idx_file = _sidecar_paths(degnorm_dir, chrom)
+    try:
+        with np.load(idx_file) as idx:
+            if 'maxcov' not in idx.files:
+                return None
+            genes, lengths, maxcov = idx['genes'].tolist(), idx['lengths'].astype(np.int64), idx['maxcov'].astype(np.float64)
+            p, pkl_size, pkl_mtime_ns = int(idx['p']), int(idx['pkl_size']), int(idx['pkl_mtime_ns'])
+        st = os.stat(pkl_file)
+        if pkl_size != st.st_size or pkl_mtime_ns != st.st_mtime_ns:
+            return None
+        if os.stat(npy_file).st_size < 4 * p * int(lengths.sum()) or len(genes) != len(lengths) or len(maxcov) != len(genes) or p < 1:
+            return None
+    except Exception:
+        return None
+    offs = np.zeros(len(genes) + 1, dtype=np.int64)
+    np.cumsum(p * lengths, out=offs[1:])
+    return dict(genes=genes, lengths=lengths, maxcov=maxcov, p=p, offsets=offs[:-1], npy_file=npy_file)
+
+
+def load_index_from_previous(degnorm_dir):
+    """
+    load_from_previous WITHOUT the coverage: the two tables and, per gene (in the reference's order: per-chromosome pickle order,
+    warm_start.py:59-97), its chromosome, length, maximum coverage and position in the chromosome's packed side-car.  None unless
+    every chromosome has an up-to-date side-car with per-gene maxima (write_sidecars).  What a rank of a sharded run needs to
+    pick and memory-map ITS genes without anybody loading the whole data set.
+    """
+    from pandas import read_csv
+    exon_df = read_csv(os.path.join(degnorm_dir, 'gene_exon_metadata.csv'), low_memory=False)
+    read_count_df = read_csv(os.path.join(degnorm_dir, 'read_counts.csv'), low_memory=False)
+    genes_df = exon_df[['chr', 'gene', 'gene_start', 'gene_end']].drop_duplicates().reset_index(drop=True)
+    keep = set(np.intersect1d(genes_df.gene, read_count_df.gene).tolist())
+    genes_df = genes_df[genes_df.gene.isin(keep)]
+    read_count_df = read_count_df[read_count_df.gene.isin(keep)]
+    sample_ids = read_count_df.columns.tolist()[2:]
+    names, chrom_of, lengths, maxcov, offsets, files, p = [], [], [], [], [], {}, None
+    for chrom in genes_df.chr.unique().tolist():
+        ix = _sidecar_index(degnorm_dir, chrom)
+        if ix is None or (p is not None and ix['p'] != p):
+            return None
+        p = ix['p']
+        files[str(chrom)] = ix['npy_file']
+        for k, g in enumerate(ix['genes']):
+            if g in keep:
+                names.append(g); chrom_of.append(str(chrom)); lengths.append(int(ix['lengths'][k]))
+                maxcov.append(float(ix['maxcov'][k])); offsets.append(int(ix['offsets'][k]))
+    if not names:
+        return None
+    genes_df = genes_df.set_index('gene').loc[names].reset_index(drop=False)
+    read_count_df = read_count_df.set_index('gene').loc[names].reset_index(drop=False)
+    return dict(genes=names, chrom=chrom_of, lengths=np.array(lengths, dtype=np.int64), maxcov=np.array(maxcov), offsets=np.array(offsets, dtype=np.int64),
+                files=files, p=int(p), read_count_df=read_count_df, genes_df=genes_df, sample_ids=sample_ids)
+
+
+def pack_genes_from_sidecars(index, positions):
+    """One packed float32 buffer (the layout dn_upload_packed takes) of the genes at `positions` of a load_index_from_previous
+    result, copied out of the memory-mapped side-cars: only these genes' pages are read."""
+    p = index['p']
+    lengths = index['lengths'][np.asarray(positions, dtype=np.int64)] if len(positions) else np.zeros(0, dtype=np.int64)
+    packed = np.empty(int(p * lengths.sum()), dtype=np.float32)
+    maps, o = {}, 0
+    for k in positions:
+        c = index['chrom'][k]
+        if c not in maps:
+            maps[c] = np.load(index['files'][c], mmap_mode='r')
+        n = p * int(index['lengths'][k])
+        packed[o:o + n] = maps[c][index['offsets'][k]:index['offsets'][k] + n]
+        o += n
+    return packed, lengths
 
 
 def _load_chrom(degnorm_dir, chrom, use_sidecar):
@@ -208,34 +285,87 @@ def run_from_warm_start(warm_start_dir, output_dir, degnorm_iter=5, nmf_iter=100
     return model
 
 
+def _copy_inputs(degnorm_dir, new_dir, chroms):
+    """what load_from_previous copies into the new output directory (warm_start.py:30-57)"""
+    shutil.copy(os.path.join(degnorm_dir, 'gene_exon_metadata.csv'), os.path.join(new_dir, 'gene_exon_metadata.csv'))
+    shutil.copy(os.path.join(degnorm_dir, 'read_counts.csv'), os.path.join(new_dir, 'read_counts.csv'))
+    for chrom in chroms:
+        os.makedirs(os.path.join(new_dir, str(chrom)), exist_ok=True)
+        shutil.copy(os.path.join(degnorm_dir, str(chrom), 'coverage_matrices_{0}.pkl'.format(chrom)),
+                    os.path.join(new_dir, str(chrom), 'coverage_matrices_{0}.pkl'.format(chrom)))
+
+
 def run_from_warm_start_mpi(comm, warm_start_dir, output_dir, degnorm_iter=5, nmf_iter=100, downsample_rate=1,
-                            skip_baseline_selection=False, minimax_coverage=0, device=None, partition='balanced'):
+                            skip_baseline_selection=False, minimax_coverage=0, device=None, partition='balanced',
+                            sharded_load=True):
     """
-    The `degnorm_mpi --warm-start-dir` chain (`__main_mpi__.py:357-456`) on one process per GPU: rank 0 reads the previous
-    run and applies the MPI CLI's gene filter (minimax coverage, take-every size, and its 9-megabase / 2^31 limits,
-    :374-376); run_gene_nmfoa_mpi ships every rank its packed share once (the reference has every worker unpickle the
-    WHOLE dictionary from a temporary file, :402-415); rank 0 writes the result files (:450-456).  A failure on rank 0
-    before the run (missing files, no genes left) is raised on every rank.  Returns the result dict on rank 0, else None.
+    The `degnorm_mpi --warm-start-dir` chain (`__main_mpi__.py:357-456`) on one process per GPU.
+    With up-to-date packed side-cars (write_sidecars) NO rank loads the whole data set: every rank reads the two tables and the
+    side-car indices (names, lengths, per-gene maxima), applies the MPI CLI's gene filter to them (minimax coverage, take-every
+    size, its 9-megabase / 2^31 limits, :374-376), derives the same partition, and memory-maps ITS genes (the reference has rank 0
+    load everything and every worker unpickle the WHOLE dictionary from a temporary file, :400-415).  Without side-cars rank 0
+    loads the pickles and run_gene_nmfoa_mpi ships every rank its packed share once.  Rank 0 writes the result files (:450-456).
+    A failure before the run (missing files, no genes left) is raised on every rank.  Returns the result dict on rank 0, else None.
     """
-    from .nmf_mpi import run_gene_nmfoa_mpi, save_results, _bcast
-    err, cov, reads, genes_df, sample_ids = None, None, None, None, None
-    if comm.rank == 0:
+    from .nmf_mpi import run_gene_nmfoa_mpi, save_results, _bcast, _allreduce, _partition, _run_shard_and_gather
+    index, err = None, None
+    if sharded_load:
         try:
-            dat = load_from_previous(warm_start_dir, output_dir)
-            cov, reads_df, genes_df = select_genes(dat['gene_cov_dict'], dat['read_count_df'], dat['genes_df'],
-                                                   minimax_coverage=minimax_coverage, downsample_rate=downsample_rate,
-                                                   mpi_limits=True)
-            sample_ids = dat['sample_ids']
-            reads = reads_df[sample_ids].values.astype(np.float64)            # __main_mpi__.py:430
-            logging.info('DegNorm will run on {0} genes, downsampling rate = 1 / {1}, {2} baseline selection.'
-                         .format(len(cov), downsample_rate, 'without' if skip_baseline_selection else 'with'))
+            index = load_index_from_previous(warm_start_dir)
+        except (IOError, OSError, ValueError, KeyError) as e:
+            index, err = None, '{0}: {1}'.format(type(e).__name__, e)
+    n_ok = int(round(_allreduce(comm, [1.0 if index is not None else 0.0])[0]))
+    if n_ok == comm.size:
+        try:
+            L, mx = index['lengths'], index['maxcov']
+            bad = (mx < minimax_coverage) | (L <= downsample_rate) | (L > 9e6) | (mx > 2147483647)      # __main__.py:229, __main_mpi__.py:374-376
+            keep = np.flatnonzero(~bad)
+            if len(keep) == 0:
+                raise ValueError('No genes available to run through DegNorm!\n'
+                                 'Check that your requested genes are in genome annotation file.')
+            sample_ids = index['sample_ids']
+            genes = [index['genes'][k] for k in keep]
+            genes_df = index['genes_df'].iloc[keep].reset_index(drop=True)
+            x = index['read_count_df'].iloc[keep][sample_ids].values.astype(np.float64)          # __main_mpi__.py:430
+            p, li_vec = index['p'], L[keep]
+            if abs(int(downsample_rate)) > 1 and not np.min(li_vec) >= abs(int(downsample_rate)):
+                raise ValueError('downsample_rate is too large; take-every size > at least one gene.')
+            parts = _partition(li_vec, comm.size, p, downsample_rate, partition, device)           # the same on every rank
+            if comm.rank == 0:
+                _copy_inputs(warm_start_dir, output_dir, list(dict.fromkeys(index['chrom'])))
+                logging.info('DegNorm will run on {0} genes, downsampling rate = 1 / {1}, {2} baseline selection; every rank '
+                             'maps its own genes from the packed side-cars.'.format(len(genes), downsample_rate,
+                                                                                    'without' if skip_baseline_selection else 'with'))
+            mine = parts[comm.rank]
+            packed, lengths = pack_genes_from_sidecars(index, [int(keep[k]) for k in mine])
         except (IOError, OSError, ValueError, KeyError) as e:
             err = '{0}: {1}'.format(type(e).__name__, e)
-    err = _bcast(comm, err)
-    if err is not None:
-        raise ValueError('warm start failed on rank 0 -- ' + err)
-    res = run_gene_nmfoa_mpi(comm, cov, reads, degnorm_iter=degnorm_iter, nmf_iter=nmf_iter, downsample_rate=downsample_rate,
-                             skip_baseline_selection=skip_baseline_selection, device=device, partition=partition)
+        n_bad = int(round(_allreduce(comm, [1.0 if err is not None else 0.0])[0]))
+        if n_bad:
+            raise ValueError('warm start failed -- ' + (err or 'on another rank'))
+        eng_kw = dict(device=device, degnorm_iter=degnorm_iter, downsample_rate=downsample_rate, nmf_iter=nmf_iter,
+                      skip_baseline_selection=skip_baseline_selection)
+        res = _run_shard_and_gather(comm, eng_kw, [genes[k] for k in mine], packed, lengths, x[mine], np.asarray(mine, dtype=np.int64),
+                                    len(genes), p, degnorm_iter, genes, li_vec, parts)
+    else:
+        err, cov, reads, genes_df, sample_ids = None, None, None, None, None
+        if comm.rank == 0:
+            try:
+                dat = load_from_previous(warm_start_dir, output_dir)
+                cov, reads_df, genes_df = select_genes(dat['gene_cov_dict'], dat['read_count_df'], dat['genes_df'],
+                                                       minimax_coverage=minimax_coverage, downsample_rate=downsample_rate,
+                                                       mpi_limits=True)
+                sample_ids = dat['sample_ids']
+                reads = reads_df[sample_ids].values.astype(np.float64)            # __main_mpi__.py:430
+                logging.info('DegNorm will run on {0} genes, downsampling rate = 1 / {1}, {2} baseline selection.'
+                             .format(len(cov), downsample_rate, 'without' if skip_baseline_selection else 'with'))
+            except (IOError, OSError, ValueError, KeyError) as e:
+                err = '{0}: {1}'.format(type(e).__name__, e)
+        err = _bcast(comm, err)
+        if err is not None:
+            raise ValueError('warm start failed on rank 0 -- ' + err)
+        res = run_gene_nmfoa_mpi(comm, cov, reads, degnorm_iter=degnorm_iter, nmf_iter=nmf_iter, downsample_rate=downsample_rate,
+                                 skip_baseline_selection=skip_baseline_selection, device=device, partition=partition)
     if comm.rank == 0:
         save_results(genes_df, estimates=res['estimates'], rho=res['rho'], x_adj=res['x_adj'],
                      ran_baseline_selection=res['ran_baseline_selection'], sample_ids=sample_ids, output_dir=output_dir)

@@ -205,6 +205,10 @@ const char *dn_init_kernel_name(dn_handle h);
  * per gene, two genes per 128-thread workgroup; 0 when the class does not exist for this sample count); one kernel launch
  * per non-empty class and outer iteration. */
 int32_t dn_split_length(dn_handle h);
+/* The same two boundaries for ANY cohort of p samples before anything is uploaded (they depend on p and on the device's
+ * register / LDS capacity, not on the data): what a host needs to deal genes to GPUs by predicted cost so that every GPU gets
+ * the same share of every class (the reference deals contiguous equal-count chunks, nmf_mpi.py:605).  0 / 0: one class.   */
+int  dn_class_lengths(dn_handle h, int32_t p, int32_t downsample_rate, int32_t *split_len, int32_t *tiny_len);
 int32_t dn_tiny_length(dn_handle h);
 double dn_class_kernel_ms(dn_handle h, int cls);
 /* First launch to last end of the class kernels of the most recent dn_baseline_iteration (they overlap).          */

@@ -43,8 +43,16 @@ def _gloo_worker(rank, world, port, out_q):
         comm = TorchComm()
         res = run_gene_nmfoa_mpi(comm, cov_dat if rank == 0 else None, G['reads'] if rank == 0 else None,
                                  degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']))
+        # what travelled: raw buffers, point to point, through rank 0 only (round 4; round 3 all-gathered pickles of everything)
+        traffic = np.array([float(comm.bytes_sent), float(comm.bytes_received)])
+        all_traffic = [np.zeros(2) for _ in range(world)]
+        import torch
+        box = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(box, torch.from_numpy(traffic))
         if rank == 0:
-            out_q.put({k: (v if k != 'estimates' else {g: e.sum(axis=1) for g, e in v.items()}) for k, v in res.items()})
+            out = {k: (v if k != 'estimates' else {g: e.sum(axis=1) for g, e in v.items()}) for k, v in res.items()}
+            out['traffic'] = np.stack([b.numpy() for b in box])
+            out_q.put(out)
         else:
             assert res is None
     finally:
@@ -67,6 +75,16 @@ def test_world_size_2_gloo_matches_reference_mpi_golden(oracle):
     np.testing.assert_array_equal(res['ran_baseline_selection'], G['mpi2_flags'])
     assert list(res['estimates'].keys()) == list(cov_dat.keys())          # original gene order (nmf_mpi.py:855)
     np.testing.assert_allclose(np.vstack(list(res['estimates'].values())), G['mpi2_est_rowsum'], rtol=1e-9)
+    # the worker received its share and nothing else: packed float32 coverage + lengths + read counts + ids; it sent back its
+    # float64 estimates + DI rows + adjusted counts + flags; rank 0 received exactly that.  Nobody holds another rank's data.
+    from degnorm_amd.utils import partition_by_cost
+    p, n_it = int(G['p']), int(G['degnorm_iter'])
+    L = np.array([c.shape[1] for c in cov_dat.values()])
+    mine = np.array(partition_by_cost(L, 2, p=p)[1])
+    share_in = 4 * p * L[mine].sum() + 8 * len(mine) + 8 * p * len(mine) + 8 * len(mine)
+    share_out = 8 * p * L[mine].sum() + 2 * 8 * p * len(mine) + n_it * len(mine)
+    assert res['traffic'][1, 1] == share_in and res['traffic'][1, 0] == share_out
+    assert res['traffic'][0, 0] == share_in and res['traffic'][0, 1] == share_out
 
 
 @pytest.fixture
