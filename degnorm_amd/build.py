@@ -55,6 +55,17 @@ def _hipcc():
     return 'hipcc'
 
 
+def build_stamp(hipcc):
+    """Compiler version and the flags the kernels are compiled with: what dn_version() reports (two builds of one source tree with
+    another compiler or other code-generation flags are different binaries; results are reproducible per binary)."""
+    try:
+        ver = [l for l in _run([hipcc, '--version']).splitlines() if 'clang version' in l or 'HIP version' in l]
+    except Exception:
+        ver = ['unknown compiler']
+    kern = ' '.join(SCHED) if 'DN_HIPCC_FLAGS' in os.environ else 'default scheduler for p = 3..12, max-ilp elsewhere'
+    return '; '.join(v.strip() for v in ver) + '; flags: ' + ' '.join(FLAGS[1:]) + '; kernel units: ' + kern + (('; defines: ' + ' '.join(EXTRA)) if EXTRA else '')
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -104,8 +115,14 @@ def build_library(force=False, verbose=False):
     api = os.path.join(CSRC, 'dn_api.hip')
     o_api = os.path.join(OBJ, 'dn_api.o')
     objs.append(o_api)
-    if force or _newer(o_api, [api] + hdr):
-        jobs.append([hipcc] + FLAGS + ['-DDN_WIDE_NT={0}'.format(WIDE_NT), '-DDN_P_MAX_TEMPLATED={0}'.format(P_LIST[-1]),
+    stamp = build_stamp(hipcc)
+    stamp_file = os.path.join(OBJ, 'build_stamp.txt')
+    if not os.path.exists(stamp_file) or open(stamp_file).read() != stamp:      # another compiler or other flags: the C-ABI unit names them
+        with open(stamp_file, 'w') as f:
+            f.write(stamp)
+    if force or _newer(o_api, [api, stamp_file] + hdr):
+        jobs.append([hipcc] + FLAGS + ['-DDN_BUILD_STAMP="{0}"'.format(stamp.replace('"', "'")),
+                                       '-DDN_WIDE_NT={0}'.format(WIDE_NT), '-DDN_P_MAX_TEMPLATED={0}'.format(P_LIST[-1]),
                                        '-DDN_P_PAIR(X)=' + ' '.join('X({0})'.format(q) for q in PAIR_P_LIST), '-c', api, '-o', o_api])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:

@@ -2357,7 +2357,8 @@ __global__ __launch_bounds__(NT * DN_UNITS, DN_KERNEL_WAVES) void k_baseline(Ite
 #endif
                         if (st_call == ST_OK) {
 #pragma unroll
-                            for (int i = 0; i < P; i++) unsafe = unsafe || (gs.u[i] < WARM_START_MIN_COMPONENT);
+                            for (int i = 0; i < P; i++)                      // a sample WITHOUT coverage in the active columns has u_i = 0 by right
+                                unsafe = unsafe || (gs.u[i] < WARM_START_MIN_COMPONENT && gs.sums[1 + P + i] > 0.0);
                         }
                         if (__builtin_amdgcn_readfirstlane((int) unsafe) != 0) {
                             dn_sync();

@@ -560,14 +560,36 @@ class ShardedNMFOA(object):
 
 
 # ----------------------------------------------------------------------------------------------- #
-def _pack_f32(mats):
-    """(p x L_g) matrices -> (packed float32, lengths int64, number of values float32 cannot hold exactly)."""
+def _pack_f32(mats, n_threads=0):
+    """(p x L_g) matrices -> (packed float32, lengths int64, number of values float32 cannot hold exactly).  The conversion runs on
+    host threads (numpy releases the GIL in the copy): rank 0 packs every share of the data set before it can ship it."""
     lengths = np.array([m.shape[1] for m in mats], dtype=np.int64)
     if len(mats) == 0:
         return np.zeros(0, dtype=np.float32), lengths, 0
-    packed = np.concatenate([np.asarray(m, dtype=np.float32).ravel() for m in mats])
-    inexact = int(sum(int(np.count_nonzero(np.asarray(m, dtype=np.float32) != m)) for m in mats if m.dtype != np.float32))
-    return packed, lengths, inexact
+    p = int(mats[0].shape[0])
+    offs = np.zeros(len(mats) + 1, dtype=np.int64)
+    np.cumsum(p * lengths, out=offs[1:])
+    packed = np.empty(int(offs[-1]), dtype=np.float32)
+    n_threads = int(n_threads) if n_threads else max(1, min(16, os.cpu_count() or 1))
+
+    def work(lo_hi):
+        bad = 0
+        for k in range(*lo_hi):
+            m = np.asarray(mats[k])
+            dst = packed[offs[k]:offs[k + 1]].reshape(m.shape)
+            np.copyto(dst, m, casting='unsafe')
+            if m.dtype != np.float32:
+                bad += int(np.count_nonzero(dst != m))
+        return bad
+    step = max(1, (len(mats) + 4 * n_threads - 1) // (4 * n_threads))
+    chunks = [(lo, min(len(mats), lo + step)) for lo in range(0, len(mats), step)]
+    if n_threads > 1 and len(mats) > 64:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=n_threads) as ex:
+            inexact = sum(ex.map(work, chunks))
+    else:
+        inexact = sum(work(c) for c in chunks)
+    return packed, lengths, int(inexact)
 
 
 def _class_lengths(device, p, downsample_rate):
