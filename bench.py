@@ -519,6 +519,7 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
     eng.reuse_buffers = True        # every step fills the same host arrays (per-gene counters, final state): a step is a repeated run
     eng.trace_columns = 8           # per iteration the 8 counters of a gene come back (n_hi_cov, calls, columns, exit, ..., solver steps), not
                                     # the dropped-bin sequence behind them (diagnostics: 9.6 MB per iteration on config 4)
+    eng.keep_packed = bool(args.redeal) and world > 1
     t_up = time.time()
     eng.load_packed(packed, lengths, p, reads, global_ids=np.asarray(my_genes, dtype=np.int64), n_total=n_genes)
     t_up = time.time() - t_up
@@ -549,6 +550,17 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
         eng.fetch_state()                                               # final rho / x_adj / x_weighted / flags: D2H inside the clock
         fetch_s.append(time.perf_counter() - tf)
 
+    redeal_info = None
+    if args.redeal and world > 1:
+        # --redeal: ONE untimed run hands over the few genes that level the measured per-gene cost of its first outer iteration
+        # (ShardedNMFOA.redeal); the timed steps then run on that partition (a production run does this once, after iteration 1)
+        eng.initialize()
+        eng.iterate(0, want_estimates=False)
+        redeal_info = eng.redeal()
+        for i in range(1, args.iters):
+            eng.iterate(i, want_estimates=False)
+        eng.fetch_state()
+        lengths, my_genes = eng._lengths.copy(), eng.global_ids.tolist()
     for _ in range(warmup):
         step()
 
@@ -604,6 +616,7 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
                                        args.nmf_iter, ', take-every {0}'.format(rate) if rate > 1 else ''),
                    'genes_per_gpu': len(my_genes),
                    'sharding': 'cost-balanced gene partition (utils.partition_by_cost), 1 all-reduce of 3p+4 f64 per outer iter',
+                   'redeal': redeal_info,
                    'per_rank': [{'genes': c[0], 'wide': c[1], 'narrow': c[2], 'pair': c[3], 'total_length': c[4]} for c in counts],
                    'step': 'initial pass + {0} outer iterations + D2H of the final rho / x_adj / x_weighted / flags '
                            '(fetch_state {1:.2f} ms per step)'.format(args.iters, 1e3 * float(np.mean(fetch_s)))},
@@ -846,6 +859,8 @@ def parse(argv=None):
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the GeneNMFOA.fit() end-to-end timing (config 2, N = 1)')
     ap.add_argument('--no-also', action='store_true', help='skip the config-4 measurement appended to the default config-2 line')
     ap.add_argument('--no-rccl', action='store_true', help='N = 1 without torchrun: do not open a one-rank RCCL process group')
+    ap.add_argument('--redeal', action='store_true',
+                    help='N > 1: before the warm-up, one untimed run re-deals the genes from the measured cost of its first outer iteration')
     ap.add_argument('--sharded-api', action='store_true',
                     help='N > 1: after the clock, also run the reference-signature API run_gene_nmfoa_mpi on the whole configuration '
                          '(rank 0 holds the float64 dict) and report scatter / run / gather per rank (`end_to_end_sharded`)')

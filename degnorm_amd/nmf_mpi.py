@@ -28,7 +28,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from .utils import split_into_chunks, partition_by_cost
+from .utils import split_into_chunks, partition_by_cost, measured_gene_cost, rebalance_moves
 from .results import write_results
 
 __all__ = ['run_gene_nmfoa_mpi', 'save_results', 'ShardedNMFOA', 'TorchComm', 'LocalComm']
@@ -264,6 +264,11 @@ class ShardedNMFOA(object):
         self.n_flagged = []                               # per outer iteration: genes sent through baseline selection (all ranks)
         self._lib_comm = False                            # True: the collectives run inside the library (attach_library_comm)
         self.library_reductions = 0
+        self.keep_packed = False                          # True: the packed float32 shard stays on the host too (redeal() needs it)
+        self.redeal_after_first = False                   # True: run() levels the measured per-gene cost over the ranks after iteration 1
+        self._packed, self._lengths = None, None
+        self.redeal_info = None
+        self._ran_saved = None                            # flags columns of the iterations before a re-deal (the device restarts its own)
 
     @property
     def dev(self):
@@ -307,6 +312,8 @@ class ShardedNMFOA(object):
         self._set_reads(reads, len(cov_mats), p, global_ids, n_total)
 
     def load_packed(self, packed, lengths, p, reads, global_ids=None, n_total=None):
+        if self.keep_packed:
+            self._packed, self._lengths = np.ascontiguousarray(packed, dtype=np.float32), np.asarray(lengths, dtype=np.int64).copy()
         if len(lengths) > 0:
             if self.trace_columns is not None and hasattr(self.dev, 'set_trace_columns'):
                 self.dev.set_trace_columns(self.trace_columns)
@@ -370,6 +377,7 @@ class ShardedNMFOA(object):
         self.x_weighted = None if on_device else self.x / self.norm_factors      # on the device: formed there, fetched by fetch_state()
         self.scale_factors = np.copy(self.norm_factors)
         self.ran_baseline_selection = np.zeros((self.n_local, self.degnorm_iter), dtype=bool)
+        self._ran_saved = None
         self._rng = np.random.RandomState(self.random_state)
         self.x_adj = None
         # The O(n p) update between two sweeps runs on the device when it offers it (dn_outer_*): the DI matrix, the
@@ -536,8 +544,113 @@ class ShardedNMFOA(object):
             if self.reuse_buffers:
                 self._state_bufs = bufs
             self.rho, self.x_adj, self.x_weighted, ran = bufs
-            self.ran_baseline_selection = ran[:, :self.degnorm_iter]
+            self.ran_baseline_selection = np.array(ran[:, :self.degnorm_iter], dtype=bool)
+            if self._ran_saved is not None:                           # the iterations before a re-deal: the device restarted its flags
+                k = self._ran_saved.shape[1]
+                self.ran_baseline_selection[:, :k] = self._ran_saved
             self._state_on_device = False
+
+    # -- re-dealing the genes from measured cost ------------------------------------------------------
+    def redeal(self, class_lengths=None, tol=1.002):
+        """
+        Level the ranks' loads from what the last outer iteration MEASURED (utils.measured_gene_cost: nmf() calls and active columns
+        per gene -- the length alone predicts neither; iteration 1's cost predicts every later one) by moving the few genes that
+        change owner (utils.rebalance_moves): their packed float32 coverage, read counts, weighted counts and flags travel point to
+        point, every rank re-uploads its new shard and the outer state continues from the weighted counts as they stand, so the
+        remaining iterations compute exactly what they would have (per-gene results do not depend on the owner; the per-sample sums
+        are added in another order: scale factors agree to round-off).  Collective: every rank calls it after the same iteration.
+        The reference deals contiguous equal-count chunks once (nmf_mpi.py:605).  Returns a summary dict (also self.redeal_info).
+        """
+        comm, size, rank = self.comm, self.comm.size, self.comm.rank
+        if size == 1:
+            return None
+        if self._packed is None:
+            raise ValueError('redeal() needs the host copy of the shard (keep_packed = True before load_packed)')
+        p, n_tot, done = self.p, self.n_total, len(self.traces)
+        if class_lengths is None and self.n_local > 0 and hasattr(self.dev, 'split_length'):
+            class_lengths = (self.dev.split_length(), self.dev.tiny_length())
+        cost_l = measured_gene_cost(self.traces[-1], self._lengths, p, class_lengths, self.downsample_rate) if self.n_local > 0 else np.zeros(0)
+        dense = np.zeros(3 * n_tot)
+        dense[self.global_ids] = cost_l
+        dense[n_tot + self.global_ids] = rank + 1.0
+        dense[2 * n_tot + self.global_ids] = self._lengths
+        dense = _allreduce(comm, dense)                               # every rank: all costs, owners, lengths (a setup collective, host path)
+        cost, owner, lens = dense[:n_tot], np.rint(dense[n_tot:2 * n_tot]).astype(np.int64) - 1, np.rint(dense[2 * n_tot:]).astype(np.int64)
+        load0 = np.bincount(owner, weights=cost, minlength=size)
+        moves = rebalance_moves(owner, cost, size, tol=tol)
+        # the state that travels with a gene
+        if self._device_outer and self._state_on_device:
+            self.fetch_state()
+        ran = np.asarray(self.ran_baseline_selection, dtype=np.uint8).reshape(self.n_local, -1)[:, :done]
+        offs = np.zeros(self.n_local + 1, dtype=np.int64)
+        np.cumsum(p * self._lengths, out=offs[1:])
+        pos = {int(g): k for k, g in enumerate(self.global_ids)}
+        pairs = OrderedDict()
+        for g, src, dst in moves:
+            pairs.setdefault((src, dst), []).append(g)
+        incoming = []
+        for (src, dst), genes in sorted(pairs.items()):              # one global order of two-rank exchanges: no cycle of waits
+            genes = sorted(genes)
+            if rank == src:
+                ks = [pos[g] for g in genes]
+                cov = np.concatenate([self._packed[offs[k]:offs[k + 1]] for k in ks])
+                _send_arrays(comm, dst, 1200 + src, (cov, self.x[ks], np.asarray(self.x_weighted)[ks], ran[ks]))
+            elif rank == dst:
+                n_val = int(p * lens[genes].sum())
+                cov, xr, xw, rn = _recv_arrays(comm, src, 1200 + src, [((n_val,), np.float32), ((len(genes), p), np.float64),
+                                                                      ((len(genes), p), np.float64), ((len(genes), done), np.uint8)])
+                incoming.append((genes, cov, xr, xw, rn))
+        gone = set(g for g, src, dst in moves if src == rank)
+        keep = [k for k, g in enumerate(self.global_ids) if int(g) not in gone]
+        rows = [(int(self.global_ids[k]), self._packed[offs[k]:offs[k + 1]], self.x[k], np.asarray(self.x_weighted)[k], ran[k]) for k in keep]
+        for genes, cov, xr, xw, rn in incoming:
+            o = 0
+            for j, g in enumerate(genes):
+                n_val = int(p * lens[g])
+                rows.append((int(g), cov[o:o + n_val], xr[j], xw[j], rn[j]))
+                o += n_val
+        rows.sort(key=lambda r: r[0])
+        ids = np.array([r[0] for r in rows], dtype=np.int64)
+        new_packed = np.concatenate([r[1] for r in rows]) if rows else np.zeros(0, dtype=np.float32)
+        new_x = np.array([r[2] for r in rows], dtype=np.float64).reshape(len(rows), p)
+        new_xw = np.array([r[3] for r in rows], dtype=np.float64).reshape(len(rows), p)
+        new_ran = np.array([r[4] for r in rows], dtype=np.uint8).reshape(len(rows), done)
+        names = None
+        if self.gene_names is not None:                               # names travel as a small object per pair
+            names = dict(zip((int(g) for g in self.global_ids), self.gene_names))
+            for (src, dst), genes in sorted(pairs.items()):
+                if rank == src:
+                    comm.send([names[g] for g in sorted(genes)], dest=dst, tag=1300 + src)
+                elif rank == dst:
+                    names.update(zip(sorted(genes), comm.recv(source=src, tag=1300 + src)))
+        # the new shard: upload, read counts, weighted counts; the iterations continue
+        scale, norm = np.copy(self.scale_factors), np.copy(self.norm_factors)
+        keep_traces, keep_hist = self.traces, (self.scale_hist, self.n_failed, self.n_flagged, self.kernel_ms, self.class_ms, self.span_ms, self.offsets_hist)
+        self._trace_bufs, self._state_bufs = {}, None
+        self.load_packed(new_packed, lens[ids], p, new_x, global_ids=ids, n_total=n_tot)
+        self.x_weighted = new_xw
+        self.ran_baseline_selection = np.zeros((self.n_local, self.degnorm_iter), dtype=bool)
+        self.ran_baseline_selection[:, :done] = new_ran.astype(bool)
+        self._ran_saved = new_ran.astype(bool)
+        self.scale_factors, self.norm_factors = scale, norm
+        self.gene_names = [names[int(g)] for g in ids] if names is not None else None
+        self._device_outer = self.device_outer and self.n_local > 0 and hasattr(self.dev, 'outer_begin')
+        if self._device_outer:
+            self.dev.outer_begin(new_xw, max(1, self.degnorm_iter))
+        self._state_on_device = False
+        self.traces = []                                              # per-gene rows of earlier iterations belong to another gene set
+        (self.scale_hist, self.n_failed, self.n_flagged, self.kernel_ms, self.class_ms, self.span_ms, self.offsets_hist) = keep_hist
+        self._traces_before_redeal = keep_traces
+        owner2 = owner.copy()
+        for g, src, dst in moves:
+            owner2[g] = dst
+        load1 = np.bincount(owner2, weights=cost, minlength=size)
+        self.owner = owner2
+        self.redeal_info = {'moves': len(moves), 'after_iteration': done, 'max_over_mean_before': float(load0.max() / load0.mean()),
+                            'max_over_mean_after': float(load1.max() / load1.mean()), 'genes_per_rank': np.bincount(owner2, minlength=size).tolist(),
+                            'bytes_moved': int(4 * p * sum(int(lens[g]) for g, _, _ in moves))}
+        return self.redeal_info
+
 
     def run(self, want_estimates=True, flat=False):
         """Returns the estimates of the last iteration: a list of (p x L) arrays, or (flat buffer, lengths) if `flat`."""
@@ -546,6 +659,8 @@ class ShardedNMFOA(object):
         for i in range(self.degnorm_iter):
             last = i == self.degnorm_iter - 1
             self.iterate(i, want_estimates=want_estimates and last)
+            if i == 0 and self.redeal_after_first and not last and self.comm.size > 1:
+                self.redeal()
             if want_estimates and last:
                 if self.n_local == 0:
                     est = (np.zeros(0), np.zeros(0, dtype=np.int64)) if flat else []
@@ -619,7 +734,7 @@ def _partition(li_vec, size, p, downsample_rate, partition, device):
 
 
 def _run_shard_and_gather(comm, eng_kw, my_names, packed, lengths, my_x, my_ids, n_genes, p, degnorm_iter,
-                          all_genes, li_vec, parts, want_estimates=True, timings=None):
+                          all_genes, li_vec, parts, want_estimates=True, timings=None, redeal=False):
     """
     Every rank: its resident shard through the engine; then rank 0 collects -- and ONLY rank 0: raw buffers point to point, in
     rank order (nmf_mpi.py:796-815 gathers the same things as pickled tuples), rows scattered back into the original gene order.
@@ -631,6 +746,7 @@ def _run_shard_and_gather(comm, eng_kw, my_names, packed, lengths, my_x, my_ids,
     t0 = time.perf_counter()
     eng = ShardedNMFOA(comm=comm, **eng_kw)
     eng.gene_names = my_names
+    eng.keep_packed = eng.redeal_after_first = bool(redeal) and size > 1 and abs(int(degnorm_iter)) > 1
     eng.load_packed(packed, lengths, p, my_x, global_ids=my_ids, n_total=n_genes)
     del packed
     tm['upload_s'] = time.perf_counter() - t0
@@ -641,6 +757,9 @@ def _run_shard_and_gather(comm, eng_kw, my_names, packed, lengths, my_x, my_ids,
     tm['run_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     logging.info('({0}/{1}) -- finished {2} genes'.format(rank + 1, size, eng.n_local))
+    if eng.redeal_info is not None:                                     # the genes changed hands after the first iteration: every rank knows the owners
+        parts = [np.flatnonzero(eng.owner == r).tolist() for r in range(size)]
+        tm['redeal'] = eng.redeal_info
     n_it = abs(int(degnorm_iter))
     mine = (flat, np.ascontiguousarray(eng.rho, dtype=np.float64).reshape(eng.n_local, p),
             np.ascontiguousarray(eng.x_adj, dtype=np.float64).reshape(eng.n_local, p),
@@ -682,7 +801,7 @@ def _run_shard_and_gather(comm, eng_kw, my_names, packed, lengths, my_x, my_ids,
 
 def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate=1, min_high_coverage=50,
                        nmf_iter=100, bins=20, n_jobs=1, skip_baseline_selection=False, random_state=123,
-                       device=None, partition='balanced', want_estimates=True, timings=None):
+                       device=None, partition='balanced', want_estimates=True, timings=None, redeal=False):
     """
     Gene-sharded DegNorm run with the reference's signature (nmf_mpi.py:555-580).  Rank 0 holds
     ``cov_dat`` (OrderedDict gene -> p x L) and ``reads_dat`` (n x p) and ships each worker its share once
@@ -690,6 +809,8 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
     device consumes: half the bytes of the reference's float64 pickles, no per-gene objects, no pickling of the data); every rank
     then keeps its genes on its own GPU.  Results come back to rank 0 only, as raw buffers (round 3 all-gathered pickles: every
     rank received every rank's estimates).
+    ``redeal`` (extra): after the first outer iteration the ranks level their MEASURED per-gene cost by handing over the few genes
+    that change owner (ShardedNMFOA.redeal: the length predicts a gene's cost poorly, its first iteration predicts the others exactly).
     ``partition`` (extra): 'balanced' deals the genes by predicted cost so that every GPU gets the same share of every gene
     class (utils.partition_by_cost with the class boundaries of THIS sample count on the device, dn_class_lengths),
     'contiguous' is the reference's equal-count chunking (nmf_mpi.py:605); per-gene results do not depend on it (the
@@ -752,7 +873,7 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
     eng_kw = dict(device=device, degnorm_iter=degnorm_iter, downsample_rate=downsample_rate, min_high_coverage=min_high_coverage,
                   nmf_iter=nmf_iter, bins=bins, skip_baseline_selection=skip_baseline_selection, random_state=random_state)
     return _run_shard_and_gather(comm, eng_kw, my_names, packed, lengths, my_x, my_ids, n_genes, p, degnorm_iter,
-                                 all_genes, li_vec, parts, want_estimates=want_estimates, timings=timings)
+                                 all_genes, li_vec, parts, want_estimates=want_estimates, timings=timings, redeal=redeal)
 
 
 def save_results(genes_df, estimates, rho, x_adj, ran_baseline_selection, sample_ids=None, output_dir='.'):

@@ -95,6 +95,65 @@ def partition_by_cost(lengths, n, p=10, downsample_rate=1, class_lengths=None):
     return [sorted(q) for q in parts]
 
 
+def measured_gene_cost(trace, lengths, p=10, class_lengths=None, downsample_rate=1):
+    """
+    Relative cost of a gene in the outer iteration its counters come from: the same model as predicted_gene_cost, with the counters
+    the kernels return in place of the guess "one call over L columns" -- trace[:, 1] = number of nmf() calls, trace[:, 2] = active
+    columns summed over them (a high-depth gene leaves after 1 call, a noisy one after 17: the length does not say which).  The cost
+    of the first outer iteration predicts every later one to a correlation of 0.99999 (round 3, profiles/round3/host_overhead_2500.txt).
+    """
+    L = np.asarray(lengths, dtype=np.float64)
+    calls, cols = np.asarray(trace[:, 1], dtype=np.float64), np.asarray(trace[:, 2], dtype=np.float64)
+    if downsample_rate > 1:
+        return cols + 64.0 * np.maximum(calls, 1.0)
+    if class_lengths is None:
+        class_lengths = P10_CLASS_LENGTHS if int(p) == 10 else (0, 0)
+    if not class_lengths[0]:
+        return cols / 256.0 + 4.0 * np.maximum(calls, 0.25)
+    cls = gene_classes(L, class_lengths[0], class_lengths[1])
+    lanes = np.where(cls == 0, 256.0, np.where(cls == 1, 128.0, 64.0))
+    per_col = np.where(cls == 0, 1.25, 1.0)
+    return (cols / lanes * per_col + 4.0 * np.maximum(calls, 0.25)) * (lanes / 64.0)      # a gene that leaves before its first call still costs its scan
+
+
+def rebalance_moves(owner, cost, n, tol=1.002, max_moves=None):
+    """
+    The FEW moves that level measured loads: starting from the current owners, repeatedly take from the most loaded part the gene
+    whose cost best fills the gap to the mean and give it to the least loaded part, until no part is above tol x mean (or no move
+    helps).  Deterministic (every rank computes the same list from the same all-reduced costs).  Returns [(gene, src, dst), ...].
+    """
+    owner = np.array(owner, dtype=np.int64)
+    cost = np.asarray(cost, dtype=np.float64)
+    n = int(n)
+    load = np.bincount(owner, weights=cost, minlength=n).astype(np.float64)
+    mean = load.mean()
+    if max_moves is None:
+        max_moves = max(8, len(cost) // 4)
+    # per part: its genes sorted by cost (ascending) for a bisect-like pick
+    members = [sorted(np.flatnonzero(owner == r).tolist(), key=lambda g: (cost[g], g)) for r in range(n)]
+    moves = []
+    while len(moves) < max_moves:
+        hi, lo = int(np.argmax(load)), int(np.argmin(load))
+        if load[hi] <= mean * tol or hi == lo or not members[hi]:
+            break
+        want = min(load[hi] - mean, mean - load[lo])
+        if want <= 0:
+            break
+        costs_hi = [cost[g] for g in members[hi]]
+        k = int(np.searchsorted(costs_hi, want, side='right')) - 1      # the most expensive gene not above the gap
+        if k < 0:
+            k = 0
+            if costs_hi[0] >= load[hi] - load[lo]:                     # even the cheapest gene would overshoot: done
+                break
+        g = members[hi].pop(k)
+        members[lo].append(g)
+        members[lo].sort(key=lambda q: (cost[q], q))
+        load[hi] -= cost[g]; load[lo] += cost[g]
+        owner[g] = lo
+        moves.append((int(g), hi, lo))
+    return moves
+
+
 def partition_by_measured_cost(cost, n):
     """
     LPT on MEASURED per-gene costs (the cycle counters of an outer iteration, trace column 7 ... see ShardedNMFOA.redeal): most

@@ -26,7 +26,7 @@ def _inputs():
     return G, cov_dat
 
 
-def _worker(rank, world, port, partition, out_q):
+def _worker(rank, world, port, partition, out_q, redeal=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
     import torch.distributed as dist
     from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi, TorchComm
@@ -34,11 +34,14 @@ def _worker(rank, world, port, partition, out_q):
     try:
         G, cov_dat = _inputs()
         comm = TorchComm()
+        tm = {}
         res = run_gene_nmfoa_mpi(comm, cov_dat if rank == 0 else None, G['reads'] if rank == 0 else None,
                                  degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), device=0,
-                                 partition=partition)
+                                 partition=partition, redeal=redeal, timings=tm)
         if rank == 0:
-            out_q.put({k: (v if k != 'estimates' else {g: e.sum(axis=1) for g, e in v.items()}) for k, v in res.items()})
+            out = {k: (v if k != 'estimates' else {g: e.sum(axis=1) for g, e in v.items()}) for k, v in res.items()}
+            out['redeal'] = tm.get('redeal')
+            out_q.put(out)
         else:
             assert res is None
     finally:
@@ -57,6 +60,31 @@ def test_two_ranks_on_the_gpu_match_reference_mpi_golden(partition):
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     G, cov_dat = _inputs()
+    np.testing.assert_allclose(res['rho'], G['mpi2_rho'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res['x_adj'], G['mpi2_x_adj'], rtol=1e-9)
+    np.testing.assert_array_equal(res['ran_baseline_selection'], G['mpi2_flags'])
+    assert list(res['estimates'].keys()) == list(cov_dat.keys())
+    np.testing.assert_allclose(np.vstack(list(res['estimates'].values())), G['mpi2_est_rowsum'], rtol=1e-9)
+
+
+def test_two_ranks_on_the_gpu_redeal_after_first_iteration():
+    """
+    ShardedNMFOA.redeal on real devices (both ranks on GPU 0 over gloo): the contiguous deal of the reference (nmf_mpi.py:605) is
+    levelled after the first outer iteration from the kernels' own counters -- coverage re-uploaded, the device-side outer state
+    restarted from the weighted counts as they stand -- and the run still gives the reference's MPI result.
+    """
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out_q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 13) % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 'contiguous', out_q, True)) for r in range(2)]
+    [p.start() for p in procs]
+    res = out_q.get(timeout=300)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    G, cov_dat = _inputs()
+    assert res['redeal'] is not None and res['redeal']['after_iteration'] == 1
+    assert res['redeal']['max_over_mean_after'] <= res['redeal']['max_over_mean_before'] + 1e-12
     np.testing.assert_allclose(res['rho'], G['mpi2_rho'], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(res['x_adj'], G['mpi2_x_adj'], rtol=1e-9)
     np.testing.assert_array_equal(res['ran_baseline_selection'], G['mpi2_flags'])

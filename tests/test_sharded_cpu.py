@@ -261,3 +261,49 @@ def test_downsampled_run_is_partition_invariant(oracle_device):
     for res in (bal, con):
         np.testing.assert_allclose(res[0]['rho'], ref[0]['rho'], rtol=1e-12, atol=1e-14)
         np.testing.assert_array_equal(res[0]['ran_baseline_selection'], ref[0]['ran_baseline_selection'])
+
+
+def test_redeal_after_first_iteration_moves_few_genes_and_changes_nothing(oracle_device):
+    """
+    ShardedNMFOA.redeal (round 4; the reference deals contiguous chunks once, nmf_mpi.py:605): a deliberately skewed deal -- rank 0
+    gets all the long genes -- is levelled after the first outer iteration from the MEASURED per-gene cost by moving a few genes
+    (coverage, read counts, weighted counts, flags travel point to point); the run then gives what the un-dealt run gives: flags
+    and DI rows per gene (1e-12: the per-sample sums are added in another order), estimates, original gene order.
+    """
+    from degnorm_amd.nmf_mpi import run_gene_nmfoa_mpi
+    from degnorm_amd import utils
+    G, cov_dat = _inputs()
+    L = np.array([c.shape[1] for c in cov_dat.values()])
+    order = np.argsort(-L)
+    skew = [sorted(order[:len(L) // 2].tolist()), sorted(order[len(L) // 2:3 * len(L) // 4].tolist()), sorted(order[3 * len(L) // 4:].tolist())]
+    out, infos = {}, {}
+    for redeal in (False, True):
+        comm = _ThreadComm(3)
+        res, tms = [None] * 3, [dict() for _ in range(3)]
+        orig = utils.partition_by_cost
+
+        def work(r, redeal=redeal, res=res, tms=tms, comm=comm):
+            res[r] = run_gene_nmfoa_mpi(comm.view(r), cov_dat if r == 0 else None, G['reads'] if r == 0 else None,
+                                        degnorm_iter=int(G['degnorm_iter']), nmf_iter=int(G['nmf_iter']), redeal=redeal, timings=tms[r])
+        import degnorm_amd.nmf_mpi as M
+        M.partition_by_cost = lambda *a, **k: [list(q) for q in skew]           # the skewed deal
+        try:
+            ts = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+            [t.start() for t in ts]
+            [t.join(timeout=600) for t in ts]
+        finally:
+            M.partition_by_cost = orig
+        assert res[1] is None and res[2] is None and res[0] is not None
+        out[redeal], infos[redeal] = res[0], tms[0].get('redeal')
+    a, b = out[False], out[True]
+    info = infos[True]
+    assert infos[False] is None and info is not None and info['after_iteration'] == 1
+    assert info['max_over_mean_before'] > 1.2 and info['max_over_mean_after'] < 1.05          # 40 genes: as level as single genes allow
+    assert 0 < info['moves'] <= len(L) // 2
+    np.testing.assert_array_equal(a['ran_baseline_selection'], b['ran_baseline_selection'])
+    np.testing.assert_allclose(b['rho'], a['rho'], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(b['x_adj'], a['x_adj'], rtol=1e-12)
+    assert list(a['estimates'].keys()) == list(b['estimates'].keys()) == list(cov_dat.keys())
+    for g in cov_dat:
+        np.testing.assert_allclose(b['estimates'][g], a['estimates'][g], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(b['rho'], G['mpi3_rho'] if 'mpi3_rho' in G.files else a['rho'], rtol=1e-9, atol=1e-12)
