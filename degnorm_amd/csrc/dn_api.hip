@@ -127,7 +127,16 @@ __global__ __launch_bounds__(256) void k_row_max(const float *__restrict__ cov, 
             const float4 *q = reinterpret_cast<const float4 *>(row + h);
             const int n4 = (L - h) >> 2;
             int j = lane;
-            for (; j + 192 < n4; j += 256) {               // four independent 16-byte loads per lane in flight
+            typedef float vf4 __attribute__((ext_vector_type(4)));
+            const vf4 *qv = reinterpret_cast<const vf4 *>(q);
+            for (; j + 448 < n4; j += 512) {               // eight independent 16-byte loads per lane in flight, read once: non-temporal
+                vf4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(qv + j + 64 * k);
+#pragma unroll
+                for (int k = 0; k < 8; k++) { row_max_acc(v[k].x, m, ok); row_max_acc(v[k].y, m, ok); row_max_acc(v[k].z, m, ok); row_max_acc(v[k].w, m, ok); }
+            }
+            for (; j + 192 < n4; j += 256) {               // four
                 const float4 a = q[j], b = q[j + 64], c = q[j + 128], d = q[j + 192];
                 row_max_acc(a.x, m, ok); row_max_acc(a.y, m, ok); row_max_acc(a.z, m, ok); row_max_acc(a.w, m, ok);
                 row_max_acc(b.x, m, ok); row_max_acc(b.y, m, ok); row_max_acc(b.z, m, ok); row_max_acc(b.w, m, ok);

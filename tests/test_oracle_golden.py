@@ -225,3 +225,47 @@ def test_pileup_run_vs_reference_golden(oracle):
     np.testing.assert_allclose(out['rho'], G['run_rho'], rtol=RT, atol=1e-12)
     np.testing.assert_allclose(out['x_adj'], G['run_x_adj'], rtol=RT)
     np.testing.assert_allclose(out['scale_factors'], G['run_scale_factors'], rtol=RT)
+
+
+def steps_golden_cases():
+    """tests/golden/steps.npz (make_golden.py steps): the fuzz generator's `steps` kind, genes stable over three runs of the reference."""
+    G = golden('steps')
+    for k in range(int(G['n'])):
+        T, bins, mhc, flag = [int(v) for v in G['prm%d' % k]]
+        yield dict(k=k, x=G['x%d' % k].astype(np.float64), scale=G['scale%d' % k], T=T, bins=bins, mhc=mhc, flag=bool(flag),
+                   rho=G['rho%d' % k], calls=G['calls%d' % k], est_rowsum=G['est_rowsum%d' % k])
+
+
+def steps_agreement(run_gene):
+    """(genes, DI mismatches, bin-sequence mismatches) of `run_gene(case) -> (rho, flag, trace row, estimate)` against the golden."""
+    n, bad_di, bad_seq = 0, [], []
+    for c in steps_golden_cases():
+        rho, flag, tr, est = run_gene(c)
+        di_ok = (tr[1] == len(c['calls']) and bool(flag) == c['flag'] and np.allclose(rho, c['rho'], rtol=1e-8, atol=1e-10)
+                 and np.allclose(est.sum(axis=1), c['est_rowsum'], rtol=1e-8, atol=1e-8))
+        if not di_ok:
+            bad_di.append(c['k'])
+        elif tr[2] != c['calls'].sum():
+            bad_seq.append(c['k'])                        # same DI and estimate through another bin of an exact tie
+        n += 1
+    return n, bad_di, bad_seq
+
+
+def test_steps_kind_vs_reference_golden(oracle):
+    """
+    G3d (round 4): piecewise-constant small-integer coverage with empty stretches -- exact ties between bin means and exact-zero
+    residuals -- is the one input kind on which round 3's randomised runs left device / oracle disagreements unexplained by the
+    reference.  Measured with the reference: 30 of 300 such genes do not agree with THEMSELVES over three runs (ARPACK's random start
+    decides a tie); on the 254 that do, the oracle must reproduce the reference's DI, flag, call count and estimate on all but a
+    handful (a tie between bin means decided by summation order: numpy sums pairwise, the oracle sequentially), and may take another
+    bin of an exact tie with the SAME DI on a few more.
+    """
+    def run(c):
+        rho, flags, trace, est = oracle.baseline_batch([c['x']], c['scale'], oracle.make_params(nmf_iter=c['T'], bins=c['bins'], min_high_coverage=c['mhc']),
+                                                       want_estimates=True)
+        return rho[0], flags[0], trace[0], est[0]
+    G = golden('steps')
+    assert int(G['tried']) == 300 and int(G['unstable']) >= 20          # the reference's own noise floor on this kind is ~10 %
+    n, bad_di, bad_seq = steps_agreement(run)
+    print('steps kind, oracle vs reference: %d genes, DI / flag / calls differ on %s, same DI through another bin on %s' % (n, bad_di, bad_seq))
+    assert n >= 250 and len(bad_di) <= 3 and len(bad_seq) <= 8
