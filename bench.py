@@ -528,8 +528,18 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
     if ctx['rccl_ranks'] is not None and not ctx['rehearsal'] and not args.torch_collective:
         # the collective of the step runs INSIDE the library (dn_comm_*: ncclAllReduce on the library's own stream, in place on its
         # device buffer); torch.distributed only carried the 128-byte communicator id to the ranks and times the barrier around the clock
-        eng.attach_library_comm()
-        lib_comm = eng.dev.comm_library()
+        try:
+            eng.attach_library_comm()
+            lib_comm = eng.dev.comm_library()
+        except Exception as e:                                          # no librccl the library can bind: the torch path of round 3 carries the step
+            sys.stderr.write('bench.py: library-side collective unavailable ({0!r}); using torch.distributed on the device buffer\n'.format(e))
+            eng._lib_comm = False
+        ok = np.array([1.0 if lib_comm is not None else 0.0])
+        if world > 1:                                                   # all ranks or none: a mixed state would deadlock the first reduction
+            ok = comm.allreduce_sum(ok)
+            if ok[0] < world and lib_comm is not None:
+                eng.dev.comm_destroy()
+                eng._lib_comm, lib_comm = False, None
     keep_packed = rank == 0 and world == 1 and config == 'c2'              # the float64 dict of end_to_end / the tie count are made from it
     if not keep_packed:
         packed = None
