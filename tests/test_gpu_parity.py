@@ -1029,3 +1029,16 @@ def test_steps_kind_vs_reference_golden(oracle):
         dev.close()
     print('steps kind, device vs reference: %d genes, DI / flag / calls differ on %s, same DI through another bin on %s' % (n, bad_di, bad_seq))
     assert n >= 250 and len(bad_di) <= 4 and len(bad_seq) <= 12
+
+
+def test_class_lengths_before_upload_match_the_upload(device):
+    """dn_class_lengths (what a host deals genes by, before anything is uploaded) == the boundaries the upload itself uses."""
+    for p in (4, 6, 10, 12):
+        covs = [synth.synth_gene(2, g, p, 200, 5000)[0] for g in range(12)]
+        pre = device.class_lengths(p)
+        device.upload(covs)
+        assert pre == (device.split_length(), device.tiny_length()) and pre[0] > pre[1] > 0
+    assert device.class_lengths(30) == (0, 0)                           # wide cohorts run as one class
+    assert device.class_lengths(50, downsample_rate=500) == (0, 0)      # so does the down-sampled regime
+    a, b = device.class_lengths(6), device.class_lengths(10)
+    assert a[0] > b[0] and a[1] > b[1]                                  # fewer samples: more columns fit on chip

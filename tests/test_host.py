@@ -273,3 +273,22 @@ def test_pass_of_the_on_chip_body_has_no_scratch_or_scalar_spill_traffic(tmp_pat
         assert not [o for o in ops if o.startswith('scratch_') or o == 'v_writelane_b32'], 'spill traffic in the pass (NT = %d)' % nt
         reg_ops = [l.strip().split()[0] for l in fn[i_reg:i_lds] if l.startswith('\t') and l.strip() and l.strip()[0] not in '.;']
         assert sum(o.startswith('v_') for o in reg_ops) == 1610
+
+
+def test_generated_dpp_ops_header_is_current(tmp_path):
+    """degnorm_amd/csrc/dn_dpp_ops.hpp is generated (tools/gen_dpp_ops.py: one inline-assembly statement per product and sample
+    count for the round-4 eigen-solver); the committed file must be what the generator writes."""
+    import importlib.util
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    committed = open(os.path.join(root, 'degnorm_amd', 'csrc', 'dn_dpp_ops.hpp')).read()
+    fake = tmp_path / 'repo'
+    (fake / 'tools').mkdir(parents=True)
+    (fake / 'degnorm_amd' / 'csrc').mkdir(parents=True)
+    shutil.copy(os.path.join(root, 'tools', 'gen_dpp_ops.py'), fake / 'tools' / 'gen_dpp_ops.py')
+    spec = importlib.util.spec_from_file_location('gen_dpp_ops_copy', str(fake / 'tools' / 'gen_dpp_ops.py'))
+    spec.loader.exec_module(importlib.util.module_from_spec(spec))
+    assert open(fake / 'degnorm_amd' / 'csrc' / 'dn_dpp_ops.hpp').read() == committed
+    for p in (2, 10, 16):
+        assert 'dpp_matvec<%d>' % p in committed and 'dpp_rowdot<%d>' % p in committed
+    assert committed.count('row_newbcast:15') == 2                      # only p = 16 reaches the last lane of a row
