@@ -355,6 +355,24 @@ def pileup_parity(device, p, scale, nmf_iter, n):
                     'generator is pinned with the reference (three stable runs per gene) in tests/golden/pileup.npz'}
 
 
+def power_steps_stats(traces, nmf_iter):
+    """
+    What the eigen-solves of the timed steps needed: per gene, trace[7] = power steps summed over its solves, trace[1] = nmf() calls,
+    each of nmf_iter + 1 solves (nmf.py:88-101) -- the mean over all solves and the distribution of the per-gene means (a cold solve of
+    ~10-25 plain steps from the uniform vector is in every call's average: 1 of 101 solves).  The squaring solver of rounds 1-3 spent
+    10 step equivalents per solve whatever the matrix.
+    """
+    steps = np.concatenate([tr[:, 7].astype(np.float64) for tr in traces])
+    solves = np.concatenate([tr[:, 1].astype(np.float64) * (nmf_iter + 1) for tr in traces])
+    m = solves > 0
+    per_gene = steps[m] / solves[m]
+    edges = [0, 3, 4, 5, 6, 7, 8, 10, 15, 1e9]
+    hist = np.histogram(per_gene, bins=edges)[0]
+    return {'mean': float(steps[m].sum() / solves[m].sum()), 'per_gene_mean_quantiles_10_50_90_99': [float(q) for q in np.percentile(per_gene, [10, 50, 90, 99])],
+            'per_gene_mean_histogram': {'edges': edges[:-1] + ['inf'], 'gene_iterations': hist.tolist()},
+            'what': 'plain power steps of top_eig_dpp per solve (its return value counts the steps plus one), warm start + shift'}
+
+
 def parity_sample(lengths, k):
     """Genes at evenly spaced length quantiles: every gene class and the whole work queue."""
     n = len(lengths)
@@ -695,6 +713,7 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
             'valu_issue_slots': {'wave_instructions': instr_a, 'slots_frac': instr_a * 4.0 / simd_cycles(avg_ms),
                                  'what': 'fp64 wave-instructions of the passes x 4 cycles / (sweep time x 2.4 GHz x 1024 SIMDs)'},
             'flop_per_column_iteration': flop_col, 'raw_count_units': raw_units,
+            'power_steps_per_solve': power_steps_stats(all_traces, args.nmf_iter),
             'stream_read_ceiling_gbps': stream_gbps,
             'traffic': traffic_all, 'traffic_info': tinfo,
             'traffic_per_kernel': dict({name_d: traffic}, **traffic_o),

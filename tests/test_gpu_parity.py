@@ -944,7 +944,12 @@ def test_randomised_differential_rounds(oracle):
         n, b = fuzz_parity.one_round(rng, _lib.Device, oracle, lines.append, 6000, kinds_menu=kinds)
         genes += n
         bad += b
-    assert genes > 800
+    # round 4: the raw-unit register-tier cohorts with genes that fill the tier exactly (+- one column) in EVERY round, pair and narrow class
+    for r in range(8):
+        n, b = fuzz_parity.one_round(rng, _lib.Device, oracle, lines.append, 6000, kinds_menu=kinds, force_p=(9, 10, 11, 12)[r % 4], tier_fill=True)
+        genes += n
+        bad += b
+    assert genes > 1000
     assert bad == 0, '\n'.join(l for l in lines if 'mismatching' in l and not l.rstrip().endswith('-> 0 mismatching genes') or l.startswith('      '))
 
 

@@ -66,12 +66,27 @@ def make_gene(rng, p, L, kind):
 KINDS = ['plain', 'plain', 'decay', 'decay', 'empty_sample', 'holes', 'steps', 'big', 'fractional', 'rank1', 'spike']
 
 
-def one_round(rng, device_cls, oracle, log, budget_cols, kinds_menu=None):
-    p = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 11, 12, 13, 14, 15, 16, 17, 19, 24, 32, 33, 47, 50, 64]))
-    rate = int(rng.choice([1, 1, 1, 1, 40, 200, 500]))
+def tier_filling_genes(rng, p):
+    """Flat, deep coverage (every base an active column) of exactly the register tier's capacity, one column less and one more -- of a
+    wavefront (pair class: where the straight-line body of csrc/dn_kernels.hpp starts) and of a 128-thread workgroup (narrow class)."""
+    rt_cols = min(12, 256 // (2 * p + (p + 1) // 2))                   # dn_kernels.hpp rt_cols<P, X16 = true>
+    out = []
+    for cap in (rt_cols * 64, rt_cols * 128):
+        for L in (cap - 1, cap, cap + 1):
+            out.append(rng.poisson(np.outer(rng.uniform(150., 400., p), np.ones(L))).astype(float))
+    return out
+
+
+def one_round(rng, device_cls, oracle, log, budget_cols, kinds_menu=None, force_p=None, tier_fill=False):
+    p = int(force_p) if force_p else int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 11, 12, 13, 14, 15, 16, 17, 19, 24, 32, 33, 47, 50, 64]))
+    rate = 1 if tier_fill else int(rng.choice([1, 1, 1, 1, 40, 200, 500]))
     n_genes = int(rng.integers(1, 90))
     covs, kinds = [], []
-    for g in range(n_genes):
+    if tier_fill:
+        covs = tier_filling_genes(rng, p)
+        kinds = ['tier_fill'] * len(covs)
+        n_genes += len(covs)
+    for g in range(len(covs), n_genes):
         if rate > 1:
             L = int(rng.integers(rate + 1, min(13 * rate, 6000) + 1)) if rng.random() < 0.8 else int(rng.integers(rate + 1, 6001))   # the reference refuses rate >= a gene's length
         else:
