@@ -625,8 +625,11 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
     else:
         counts = [(len(my_genes), int(wide.sum()), int((~wide & ~pair).sum()), int(pair.sum()), float(np.sum(lengths)))]
     if rank != 0:
+        try:
+            eng.dev.close()                                             # the handle (and its RCCL communicator) goes now, not at interpreter exit
+        except Exception:
+            pass
         if world > 1 and args.sharded_api:
-            eng.dev.close()                                             # the API run opens its own handles
             end_to_end_sharded(ctx, cfg, p, n_genes, args, rate)        # collective: rank 0 joins after its post-clock checks
         return None
 
