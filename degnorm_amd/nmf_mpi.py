@@ -119,7 +119,9 @@ class TorchComm(object):
     bytes_sent = 0
     bytes_received = 0
 
-    def send_array(self, arr, dest):
+    def send_array(self, arr, dest, pending=None):
+        """`pending` (a list): do not wait -- the (request, buffer) pairs are appended to it and the caller waits with wait_sends()
+        (rank 0 packs the next rank's share while this one travels)."""
         a = np.ascontiguousarray(arr)
         flat = a.reshape(-1).view(np.uint8)
         for lo in range(0, flat.size, self.CHUNK_BYTES):
@@ -129,8 +131,17 @@ class TorchComm(object):
             t = self.torch.from_numpy(piece)
             if self.backend == 'nccl':
                 t = t.to(self.device)
-            self.dist.send(t, dst=dest, group=self.group)
+            if pending is None:
+                self.dist.send(t, dst=dest, group=self.group)
+            else:
+                pending.append((self.dist.isend(t, dst=dest, group=self.group), t, a))
         self.bytes_sent += int(flat.size)
+
+    @staticmethod
+    def wait_sends(pending):
+        for req, _, _ in pending:
+            req.wait()
+        del pending[:]
 
     def recv_array(self, shape, dtype, source):
         out = np.empty(shape, dtype=dtype)
@@ -192,12 +203,15 @@ def _bcast(comm, obj):
     return comm.recv(source=0, tag=555 + comm.rank)
 
 
-def _send_arrays(comm, dest, tag, arrays):
-    """numpy arrays to one rank: as raw buffers when the communicator can (TorchComm.send_array), else as one object (the
-    reference's own way: mpi4py pickles, nmf_mpi.py:627)."""
+def _send_arrays(comm, dest, tag, arrays, pending=None):
+    """numpy arrays to one rank: as raw buffers when the communicator can (TorchComm.send_array; with `pending` without waiting),
+    else as one object (the reference's own way: mpi4py pickles, nmf_mpi.py:627)."""
     if hasattr(comm, 'send_array'):
         for a in arrays:
-            comm.send_array(a, dest)
+            if pending is not None and hasattr(comm, 'wait_sends'):
+                comm.send_array(a, dest, pending)
+            else:
+                comm.send_array(a, dest)
     else:
         comm.send(tuple(np.ascontiguousarray(a) for a in arrays), dest=dest, tag=tag)
 
@@ -853,13 +867,16 @@ def run_gene_nmfoa_mpi(comm, cov_dat, reads_dat, degnorm_iter=5, downsample_rate
 
     if rank == 0:
         n_inexact = 0
-        for r in range(size - 1, -1, -1):                                # own share last: one packed copy alive at a time
+        pending = []
+        for r in range(size - 1, -1, -1):                                # own share last; a share travels while the next one is packed
             idx = parts[r]
             packed, lengths, bad = _pack_f32([cov_dat[all_genes[k]] for k in idx])
             n_inexact += bad
             if r > 0:
                 comm.send(([all_genes[k] for k in idx], int(packed.size)), dest=r, tag=333 + r)      # names + sizes: the only pickle
-                _send_arrays(comm, r, 444 + r, (packed, lengths, x[idx], np.asarray(idx, dtype=np.int64)))
+                _send_arrays(comm, r, 444 + r, (packed, lengths, x[idx], np.asarray(idx, dtype=np.int64)), pending)
+        if pending:
+            comm.wait_sends(pending)
         if n_inexact:
             logging.warning('{0} coverage values are not exactly representable in float32; they were rounded on upload.'.format(n_inexact))
         my_names, my_x, my_ids = [all_genes[k] for k in parts[0]], x[parts[0]], np.asarray(parts[0], dtype=np.int64)

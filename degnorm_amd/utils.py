@@ -79,19 +79,22 @@ def partition_by_cost(lengths, n, p=10, downsample_rate=1, class_lengths=None):
         class_lengths = P10_CLASS_LENGTHS if int(p) == 10 else (0, 0)
     cost = predicted_gene_cost(L, p, downsample_rate, class_lengths)
     cls = gene_classes(L, class_lengths[0], class_lengths[1]) if downsample_rate <= 1 else np.zeros(len(L), dtype=np.int64)
-    order = np.lexsort((np.arange(len(L)), -cost))                           # most expensive first, stable
+    order = np.lexsort((np.arange(len(L)), -cost)).tolist()                  # most expensive first, stable
     parts = [[] for _ in range(n)]
-    load = np.zeros(n)
-    ncls = np.zeros((n, 3), dtype=np.int64)
+    load = [0.0] * n                                                         # plain lists: n is small, 20 000 numpy calls are not
+    ncls = [[0, 0, 0] for _ in range(n)]
+    cost_l, cls_l = cost.tolist(), cls.tolist()
     for g in order:
-        c = cls[g]
-        # least loaded part; among near-equal loads (within one gene's cost) the one with the fewest genes of this class
-        lo = load.min()
-        cand = np.flatnonzero(load <= lo + 0.5 * cost[g])
-        r = int(cand[np.argmin(ncls[cand, c])])
-        parts[r].append(int(g))
-        load[r] += cost[g]
-        ncls[r, c] += 1
+        c, cg = cls_l[g], cost_l[g]
+        # least loaded part; among near-equal loads (within one gene's cost) the first one with the fewest genes of this class
+        thr = min(load) + 0.5 * cg
+        r, fewest = -1, None
+        for k in range(n):
+            if load[k] <= thr and (fewest is None or ncls[k][c] < fewest):
+                r, fewest = k, ncls[k][c]
+        parts[r].append(g)
+        load[r] += cg
+        ncls[r][c] += 1
     return [sorted(q) for q in parts]
 
 
