@@ -52,6 +52,7 @@ struct GState {
 };                              // iterations below (one step per pass) get 5x that many
 __shared__ GState g_st;
 __shared__ double g_rows_tot[256];     // nmf_rows: the wave's Gram totals (<= 78) and the solver's zero slot
+__shared__ double g_rows_dsel[80];     // nmf_rows: 1.0 at the packed indices of the Gram diagonal (the reducing lane applies the shift there)
 
 __device__ __forceinline__ void tile_sum(double (&part)[TI])          // totals left in g_sm.tot[0..TI)
 {
@@ -228,6 +229,13 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             v[j] = 0.0;
         }
         if (lane == 0) tot[ROWS_ZSLOT] = 0.0;
+        for (int e = lane; e < NGS; e += 64) {
+            bool diag = false;
+#pragma unroll
+            for (int i = 0; i < NSM; i++) diag = diag || (e == i * (i + 1) / 2 + i);
+            g_rows_dsel[e] = diag ? 1.0 : 0.0;
+        }
+        wave_fence();
         const double c = 1.0 / sqrt((double) T);                        // nmf.py:91
         Solver<NSM> sol;                                                // carried solver state (iterate, scale, shift)
         double theta = 0.0;
@@ -250,16 +258,19 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             for (int i = 0; i < NSM; i++)
 #pragma unroll
                 for (int j = 0; j <= i; j++) C[i * (i + 1) / 2 + j] = a[i] * a[j];
-            wave_round_store<NGS, 0, double>(C, tot, lane, 0.0, tot, false);      // ceil(NGS / 64) reduce-scatter rounds
+            // ceil(NGS / 64) reduce-scatter rounds; the lane that ends up with a diagonal entry subtracts the call's shift as it stores
+            // it (round 4: the shift is fixed after the cold solve -- the trace, its test and the read-modify-write of the diagonal
+            // with its two fences are the cold solve's alone; x + lambda >= x entry by entry, so a matrix that was not zero stays so)
             wave_fence();
-            double tr = 0.0;
+            wave_round_store<NGS, 0, double>(C, tot, lane, t < 0 ? 0.0 : sol.shift(), g_rows_dsel, true);
+            wave_fence();
+            if (t < 0) {
+                double tr = 0.0;
 #pragma unroll
-            for (int i = 0; i < NSM; i++) tr += tot[i * (i + 1) / 2 + i];
-            if (!(tr > 0.0)) { st = ST_ARPACK; break; }
-            if (t < 0) sol.cold(tr, v);
-            wave_fence();
-            if (lane < NSM) tot[lane * (lane + 1) / 2 + lane] -= sol.shift();   // the solver takes G - mu I
-            wave_fence();
+                for (int i = 0; i < NSM; i++) tr += tot[i * (i + 1) / 2 + i];
+                if (!(tr > 0.0)) { st = ST_ARPACK; break; }
+                sol.cold(tr, v);
+            }
             int r;
             if constexpr (SAFE) {                                       // the safe repeat (k_baseline_gen decides): block by block, unshifted
                 r = solve_by_blocks<NSM>(sol, tot, ROWS_ZSLOT, v, theta, g_st.max_steps, n);
