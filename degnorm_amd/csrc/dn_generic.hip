@@ -215,6 +215,11 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
 {
     constexpr int NGS = NSM * (NSM + 1) / 2;  // packed Gram entries: 10, 36, 78
     const bool first = first_i != 0;
+    // arguments of a non-inlined function arrive in vector registers: as scalars the loop's tests (last iteration, cold solve, step
+    // cap) are scalar branches, not exec masks with a branch around either side
+    T = __builtin_amdgcn_readfirstlane(T);
+    n = __builtin_amdgcn_readfirstlane(n);
+    p = __builtin_amdgcn_readfirstlane(p);
     if (wave_id() == 0) {
         const int lane = lane_id();
         const bool live = lane < p;
@@ -241,9 +246,10 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
         double theta = 0.0;
         int steps = 0, st = ST_OK;
         bool noconv = false;
+        const int maxs = __builtin_amdgcn_readfirstlane(g_st.max_steps);
 #pragma clang loop unroll(disable)
         for (int t = -1; t < T; t++) {                                  // t = -1: SVD of x itself (nmf.py:88)
-            if (t >= 0) {
+            if (__builtin_expect(t >= 0, 1)) {
                 double ts = 0.0;
 #pragma unroll
                 for (int j = 0; j < NSM; j++) ts = fma(a[j], v[j], ts);  // u_s sigma
@@ -264,7 +270,7 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             wave_fence();
             wave_round_store<NGS, 0, double>(C, tot, lane, t < 0 ? 0.0 : sol.shift(), g_rows_dsel, true);
             wave_fence();
-            if (t < 0) {
+            if (__builtin_expect(t < 0, 0)) {
                 double tr = 0.0;
 #pragma unroll
                 for (int i = 0; i < NSM; i++) tr += tot[i * (i + 1) / 2 + i];
@@ -273,10 +279,10 @@ __device__ __attribute__((noinline)) void nmf_rows(const float *Fb, double *rs, 
             }
             int r;
             if constexpr (SAFE) {                                       // the safe repeat (k_baseline_gen decides): block by block, unshifted
-                r = solve_by_blocks<NSM>(sol, tot, ROWS_ZSLOT, v, theta, g_st.max_steps, n);
-            } else r = sol.run(tot, ROWS_ZSLOT, v, theta, t == T - 1, g_st.max_steps, t < 0);
+                r = solve_by_blocks<NSM>(sol, tot, ROWS_ZSLOT, v, theta, maxs, n);
+            } else r = sol.run(tot, ROWS_ZSLOT, v, theta, t == T - 1, maxs, t < 0);
             steps += r;
-            if (r > g_st.max_steps) noconv = true;
+            noconv = noconv || r > maxs;
             wave_fence();
         }
         if (st == ST_OK) {

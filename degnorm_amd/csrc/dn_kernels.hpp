@@ -718,7 +718,7 @@ __device__ __forceinline__ int top_eig_dpp(const double *tot, int zslot, double 
     double q = st.q;
     bool conv = wave_any(d2 * q <= 1e-26);
     int extra = 0;                                                         // looks beyond the first
-    if (!conv || probe) {
+    if (__builtin_expect(!conv || probe, 0)) {
         if (!wave_any(m2 > 0.0)) { theta = 0.0; return steps; }           // H v = 0: nothing to find (theta = 0 tells the caller)
         while (steps < maxs) {
             const double d2_prev = d2;
@@ -736,9 +736,9 @@ __device__ __forceinline__ int top_eig_dpp(const double *tot, int zslot, double 
     DN_MARK("solver_checked");
 #pragma unroll
     for (int i = 0; i < P; i++) u[i] = bcast_lane<P>(ua, i);
-    if (exact_theta) theta = dpp_rowdot<P>(dpp_matvec<P>(Hr, ua), ua) / sc + mu;     // Rayleigh quotient u^T (G - mu I) u + mu
-    else if (cold) theta = fma(ylen, __builtin_amdgcn_rcp(sc), mu);
-    if (cold) {                                                            // shift and scale of this call's warm solves
+    if (__builtin_expect(exact_theta, 0)) theta = dpp_rowdot<P>(dpp_matvec<P>(Hr, ua), ua) / sc + mu;     // Rayleigh quotient u^T (G - mu I) u + mu
+    else if (__builtin_expect(cold, 0)) theta = fma(ylen, __builtin_amdgcn_rcp(sc), mu);
+    if (__builtin_expect(cold, 0)) {                                       // shift and scale of this call's warm solves
         const double dgl = tot[r < P ? r * (r + 1) / 2 + r : zslot];
         const double tr = fma((double) P, mu, dpp_rowdot<P>(dgl, 1.0));
         const double mn = (tr - theta) * (1.0 / (double) (P > 1 ? P - 1 : 1));
