@@ -820,13 +820,31 @@ __device__ __forceinline__ void mg_gram_pass(const float *x, int L, int p)
 //     sum_c x_i x_j = 65536 HH_ij + 256 (HL_ij + HL_ji) + LL_ij + K (r_i + r_j) + n K^2,     K = 32 896, r_i = 256 sum_c h'_i + sum_c l'_i
 // with three byte Gram matrices accumulated EXACTLY in int32 by v_mfma_i32_16x16x64_i8 (16 cycles for 64 columns of a 16 x 16
 // tile; the fp64 form takes 64 cycles for 4 columns: 160 MFMA-cycles per column of a 64-row matrix against 10 here).  p <= 63.  As in the
-// fp64 pass which columns share an instruction does not matter, so lane (i = l & 15, kb = l >> 4) loads the 16 consecutive
-// counts c0 + 16 kb .. + 15 of row 16 t + i (64 contiguous bytes; a row's 256 bytes per wave) and the same registers serve as
-// A and as B operand.  Row p is a row of ones in l' (zeros in h'): r_j falls out of the same products.  Every wave takes
+// fp64 pass which columns share an instruction does not matter, so load q = 0..3 of lane (i = l & 15, kb = l >> 4) takes the four
+// counts c0 + 16 q + 4 kb .. + 3 of row 16 t + i: the four lanes of a row read 64 CONTIGUOUS bytes per load instruction (one whole
+// sector per row and instruction; the per-lane-contiguous form of round 3 touched 64 sectors for a quarter each), a row's 256 bytes
+// per wave in four instructions, and the same registers serve as A and as B operand.  Row p is a row of ones in l' (zeros in h'): r_j falls out of the same products.  Every wave takes
 // 64-column groups round-robin; a wave's int32 tiles hold at most 2 x 16 384 x (L / 4) -- genes longer than 2^17 bases take
 // the fp64 pass.  The tiles are combined in fp64 (sums of integers below 2^53: exact) into g_mg like the fp64 pass's.
 // ---------------------------------------------------------------------------------------------------
 typedef int dn_int4 __attribute__((ext_vector_type(4)));
+#ifndef DN_I8_ROWSEG
+#define DN_I8_ROWSEG 1          // 1: a load instruction reads 64 contiguous bytes per row (0: round 3's 64 contiguous bytes per LANE)
+#endif
+constexpr int I8_LK = DN_I8_ROWSEG ? 4 : 16, I8_Q = DN_I8_ROWSEG ? 16 : 4;     // column offset per lane group / per load
+#if defined(DN_PASS1_NT) && DN_PASS1_NT
+#define DN_P1_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define DN_P1_LOAD(ptr) (*(ptr))
+#endif
+#ifndef DN_PASS2_NT
+#define DN_PASS2_NT 1           // pass 2 is the last use of the gene's bytes: non-temporal loads (-5 % on the kernel)
+#endif
+#if DN_PASS2_NT
+#define DN_P2_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define DN_P2_LOAD(ptr) (*(ptr))
+#endif
 
 template <int TR>
 __device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L, int p)
@@ -843,7 +861,7 @@ __device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L,
 #pragma unroll
     for (int t = 0; t < TR; t++) {
         const int row = 16 * t + li;
-        rowp[t] = (gF_cptr) x + (size_t) (row < p ? row : 0) * L + 16 * lk;
+        rowp[t] = (gF_cptr) x + (size_t) (row < p ? row : 0) * L + I8_LK * lk;
         keep[t] = row < p ? 0xffffffffu : 0u;                               // padding rows: zero bytes (after the offset)
         ones[t] = row == p ? 0x01010101u : 0u;                              // the row of ones (in l')
     }
@@ -868,27 +886,45 @@ __device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L,
             }
     };
     const int nfull = L / 64;
-#pragma clang loop unroll(disable)
-    for (int g = w; g < nfull; g += W) {
-        dn_int4 H[TR], Lo[TR];
+    // Round 4: the loop is rotated like pass 2's -- the loads of the wave's NEXT group follow the conversion of each row tile into the
+    // registers it just freed, so a group's 16 loads are in flight while this one's 40 matrix instructions run (two waves per SIMD:
+    // without it a wave's share of the memory pipe stood empty through its conversions and products).  Only the last row tile has
+    // rows beyond the samples (padding, the row of ones): the others take their bytes as they are.
+    if (w < nfull) {
+        dn_f4 raw[TR][4];
 #pragma unroll
-        for (int t = 0; t < TR; t++) {
-            dn_f4 v[4];
+        for (int t = 0; t < TR; t++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = *(gF4_cptr) (rowp[t] + 64 * g + 4 * q);
+            for (int q = 0; q < 4; q++) raw[t][q] = DN_P1_LOAD((gF4_cptr) (rowp[t] + 64 * w + I8_Q * q));
+        auto trip = [&](auto more_c, int gn) {
+            constexpr bool MORE = decltype(more_c)::value;
+            dn_int4 H[TR], Lo[TR];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                unsigned lo, hi;
-                pack4(v[q], lo, hi);
-                Lo[t][q] = (int) ((lo & keep[t]) | ones[t]);
-                H[t][q] = (int) (hi & keep[t]);
+            for (int t = 0; t < TR; t++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned lo, hi;
+                    pack4(raw[t][q], lo, hi);
+                    if (t == TR - 1) { lo = (lo & keep[t]) | ones[t]; hi &= keep[t]; }
+                    Lo[t][q] = (int) lo;
+                    H[t][q] = (int) hi;
+                }
+                if constexpr (MORE) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) raw[t][q] = DN_P1_LOAD((gF4_cptr) (rowp[t] + 64 * gn + I8_Q * q));
+                }
             }
-        }
-        products(H, Lo);
+            if constexpr (MORE) __builtin_amdgcn_sched_barrier(0);         // the loads stay in front of the products (the scheduler sinks them to save registers)
+            products(H, Lo);
+        };
+        int g = w;
+#pragma clang loop unroll(disable)
+        for (; g + W < nfull; g += W) trip(std::true_type{}, g + W);
+        trip(std::false_type{}, 0);
     }
     if ((L & 63) && w == nfull % W) {                                        // the partial last group: columns beyond L are zero bytes
         dn_int4 H[TR], Lo[TR];
-        const int c = 64 * nfull + 16 * lk;
+        const int c = 64 * nfull + I8_LK * lk;
 #pragma unroll
         for (int t = 0; t < TR; t++) {
 #pragma unroll
@@ -897,8 +933,8 @@ __device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L,
                 unsigned m = 0;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int col = c + 4 * q + e;
-                    v[e] = col < L ? rowp[t][64 * nfull + 4 * q + e] : 0.0f;
+                    const int col = c + I8_Q * q + e;
+                    v[e] = col < L ? rowp[t][64 * nfull + I8_Q * q + e] : 0.0f;
                     m |= col < L ? (0xffu << (8 * e)) : 0u;
                 }
                 unsigned lo, hi;
@@ -1032,12 +1068,22 @@ __device__ __forceinline__ int mg_solve(int p, int maxs, double *u_out)
 // the block adds them up once per gene (register reduce-scatter per wave, 32 rows per round).  u is read from LDS with
 // broadcast loads.  One read of the gene instead of the two of the row-tiled form this replaces (s_j staged in LDS, rows
 // walked in tiles of 8: 27.5 GB more traffic on config 4).
-template <int RC>                                                    // row capacity of this instantiation (p <= RC), a multiple of 8
+// Round 4 (tools/ubench/strided_rows.hip, tools/init_ab.py): the memory system gives this pair of passes 6.5-7 TB/s of algorithmic
+// bytes -- with the arithmetic of both loops in place -- where the kernel's loops reached 4.4; what was missing are loads in flight
+// while a wave computes (two waves per SIMD: a wave that issues, waits, then computes for ~3 000 cycles leaves its share of the
+// memory pipe empty for that long).  So (i) the loop is ROTATED: the clamped-sum statement of row i is followed by the load of row
+// i of the wave's NEXT block into the register it just freed -- a full block of loads in flight through the second half of every
+// trip at no register cost; (ii) the blocks are walked from the gene's END: what pass 1 read last is read first, while it still
+// sits in the Infinity Cache / L2 (the 512 resident workgroups read ~280 MB between a byte's two uses otherwise), with
+// non-temporal loads (the last use of these bytes); (iii) a row's address is one 32-bit vector add away from the previous row's
+// (scalar block base + lane offset; the running 64-bit scalar base cost four scalar instructions per load); (iv) the block that
+// the gene's end leaves partial is done first, on its own, under the one exec mask it needs.
+template <int RC>                                                    // row capacity of this instantiation (p <= RC, p > RC - 8), a multiple of 8
 __device__ __attribute__((noinline)) void mg_pass2(const float *x_, int L, int p)
 {
     constexpr int W = NT / 64;
     const int tid = threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
-    const float *x = uniform_ptr(x_);                                   // row bases stay in scalar registers: loads take saddr + lane offset
+    const float *x = uniform_ptr(x_);                                   // block bases stay in scalar registers: loads take saddr + lane offset
     L = __builtin_amdgcn_readfirstlane(L);
     p = __builtin_amdgcn_readfirstlane(p);
     // rows p .. RC - 1 are walked like the others, without a branch: their u is 0 (no part in s_j), they re-read row p - 1
@@ -1048,33 +1094,61 @@ __device__ __attribute__((noinline)) void mg_pass2(const float *x_, int L, int p
 #pragma unroll
     for (int i = 0; i < RC; i++) acc[i] = 0.0;
     typedef const char __attribute__((address_space(1))) *gbyte_cptr;
-    const long long Lb = (long long) L * 4;                             // row pitch in bytes
-#pragma clang loop unroll(disable)
-    for (int k0 = 64 * w; k0 < L; k0 += 64 * W) {
-        const bool valid = k0 + lane < L;
-        const unsigned voff = 4u * (unsigned) (valid ? lane : L - 1 - k0);   // clamped: no branch around the loads
-        gbyte_cptr row = (gbyte_cptr) (x + k0);
-        float xv[RC];
+    const unsigned Lb = 4u * (unsigned) L;                              // row pitch in bytes (a gene's RC rows stay below 4 GB: L <= 2^24, checked at upload)
+    // offset of row i + 1 from row i: the pitch, or 0 once the rows run out (only the last seven rows of an instantiation can)
+    auto step = [&](int i) -> unsigned { return (i + 1 <= RC - 8 || i + 1 < p) ? Lb : 0u; };
+    float xv[RC];
+    auto load_block = [&](int k0, unsigned off) {                       // all rows of the 64 columns from k0 (off: this lane's byte offset in the block)
+        gbyte_cptr blk = (gbyte_cptr) (x + k0);
+        asm volatile("" : "+v"(off));                                   // (the row offsets are formed as the rows are walked: hoisted, they are 2 RC registers)
 #pragma unroll
-        for (int i = 0; i < RC; i++) {
-            xv[i] = *(gF_cptr) (row + voff);                            // scalar base + 32-bit lane offset
-            row += (i + 1 < p) ? Lb : 0;
-            asm volatile("" : "+s"(row));                               // one running scalar base (else every row's address is formed on its own)
-        }
+        for (int i = 0; i < RC; i++) { xv[i] = DN_P2_LOAD((gF_cptr) (blk + off)); off += step(i); }
+    };
+    auto dot = [&]() {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int i = 0; i < RC; i += 2) {
             s0 = fma(g_st.u[i], (double) xv[i], s0);
             s1 = fma(g_st.u[i + 1], (double) xv[i + 1], s1);
         }
-        if (valid) {                                                    // lanes beyond the gene's end add nothing (one exec mask, no per-element select)
-            const double sj = s0 + s1;
+        return s0 + s1;
+    };
+    const int nfull = L >> 6;
+    if ((L & 63) && w == nfull % W) {                                   // the partial last block: lanes beyond the gene's end re-read its last column and add nothing
+        const int k0 = 64 * nfull;
+        const bool valid = k0 + lane < L;
+        load_block(k0, 4u * (unsigned) (valid ? lane : L - 1 - k0));
+        const double sj = dot();
+        if (valid) {
 #pragma unroll
             for (int i = 0; i < RC; i++) {
                 asm volatile("" : "+v"(xv[i]));                         // convert again here: keeping the RC doubles of the dot product alive spills them
                 acc[i] += fmax(g_st.u[i] * sj, (double) xv[i]);         // est[est < x] = x   nmf.py:119
             }
         }
+    }
+    if (w < nfull) {                                                    // the full blocks w, w + W, ... from the last one down
+        int b = (nfull - 1 - w) / W * W + w;
+        const unsigned off0 = 4u * (unsigned) lane;
+        load_block(64 * b, off0);
+        // one trip: the sums of block b, and (MORE) the loads of the wave's next block b - W behind them row by row
+        auto trip = [&](auto more_c, int k0n) {
+            constexpr bool MORE = decltype(more_c)::value;
+            const double sj = dot();
+            gbyte_cptr blk = (gbyte_cptr) (x + k0n);
+            unsigned off = off0;
+            asm volatile("" : "+v"(off));
+#pragma unroll
+            for (int i = 0; i < RC; i++) {
+                asm volatile("" : "+v"(xv[i]));
+                const double xd = (double) xv[i];
+                if constexpr (MORE) { xv[i] = DN_P2_LOAD((gF_cptr) (blk + off)); off += step(i); }
+                acc[i] += fmax(g_st.u[i] * sj, xd);                     // est[est < x] = x   nmf.py:119
+            }
+        };
+#pragma clang loop unroll(disable)
+        for (; b >= W; b -= W) trip(std::true_type{}, 64 * (b - W));
+        trip(std::false_type{}, 0);
     }
 #pragma unroll
     for (int i0 = 0; i0 < RC; i0 += 32) {
@@ -1108,7 +1182,7 @@ __global__ __launch_bounds__(NT, 2) void k_ratio_svd_mg(InitArgs A)
         const long long ts0 = __builtin_amdgcn_s_memtime();
         long long ts1 = ts0, ts2 = ts0;
 #endif
-        if (L < 2) status = ST_VALUE_ERROR;
+        if (L < 2 || L > (1 << 24)) status = ST_VALUE_ERROR;             // (pass 2 addresses a gene's rows by 32-bit byte offsets)
         else {
             const bool bytes_ok = TR <= 4 && A.x16 && A.x16[g] != 0 && L <= (1 << 17) && !A.force_fp64;     // else: the fp64 matrix cores
             if (bytes_ok) {
