@@ -705,10 +705,27 @@ __device__ __forceinline__ int top_singular_raw(const float *x, int L, int p)
 //   pass 2  one column per lane: s_j = u . x_j from the p counts of the column (registers), per-lane partial sums of
 //           max(u_i s_j, x_ij) for every row kept in registers for the whole gene, reduced once at the end.
 // ---------------------------------------------------------------------------------------------------
+// The two streaming passes are inlined into the kernel (round 4): as functions of their own they saved and restored ~110 callee-saved
+// vector registers per call -- 55 KB of scratch traffic per wave and call, 440 KB per gene next to the gene's own 2 x 550 KB
+// (3.94 against 4.29 ms on the 16 000-gene slice; DN_MG_INLINE=0 builds the functions).
+#ifndef DN_MG_INLINE
+#define DN_MG_INLINE 1
+#endif
+#if DN_MG_INLINE
+#define DN_MG_FN __device__ __forceinline__
+#else
+#define DN_MG_FN __device__ __attribute__((noinline))
+#endif
 constexpr int MG_ROWS = 80;                  // 5 tiles of 16: p <= 64 samples + the row of ones
 constexpr int MG_LD = MG_ROWS + 1;           // LDS row stride in doubles (odd: the column walk of the solver is conflict-light)
 __shared__ double g_mg[MG_ROWS * MG_LD];
 __shared__ double g_mv[2][MG_ROWS];
+#ifdef DN_STAMP
+__shared__ long long g_mg_ts[8];          // diagnostic build: clock reads inside pass 1 (thread 0)
+#define DN_MG_TS(k) do { if (threadIdx.x == 0) g_mg_ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DN_MG_TS(k) do { } while (0)
+#endif
 
 template <int TR>
 __device__ __forceinline__ void mg_gram_pass(const float *x, int L, int p)
@@ -828,6 +845,51 @@ __device__ __forceinline__ void mg_gram_pass(const float *x, int L, int p)
 // the fp64 pass.  The tiles are combined in fp64 (sums of integers below 2^53: exact) into g_mg like the fp64 pass's.
 // ---------------------------------------------------------------------------------------------------
 typedef int dn_int4 __attribute__((ext_vector_type(4)));
+
+// The 64-bit integer sums of the byte Gram matrices (mg_gram_pass_i8 left them where the matrix goes) -> the matrix in fp64: every
+// entry converted, the offsets of the byte representation added, the mirror image written.  r_i = 256 sum h'_i + sum l'_i sits in row p
+// (the row of ones); x = 256 h' + l' + K.  Wave w takes rows w, w + 4, ..., lane = column; all LDS reads first, one barrier, then the
+// writes.  A function of its own (like mg_solve): inside the kernel's body it shares the register allocation of the streaming loops,
+// which parks loop-invariant values in scratch and fetches them back here one dependent round trip at a time (19 k cycles per gene).
+template <int TR>
+__device__ __attribute__((noinline)) void mg_finalize_i8(int L, int p)
+{
+    constexpr int W = NT / 64;
+    constexpr int R = 16 * TR, NK = R / W;
+    constexpr double K = 32896.0;
+    const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
+    L = __builtin_amdgcn_readfirstlane(L);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const long long *g_mg64 = reinterpret_cast<const long long *>(g_mg);
+    const double nK2 = (double) L * K * K, LK = (double) L * K;
+    const int c = lane < R ? lane : R - 1, ct = c >> 4;
+    const bool col_live = c < p;
+    long long raw[NK], rawr[NK];
+    const long long rawc = g_mg64[p * MG_LD + c];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        raw[k] = g_mg64[(w + W * k) * MG_LD + c];
+        rawr[k] = g_mg64[p * MG_LD + (w + W * k)];
+    }
+    __syncthreads();                                                         // every raw sum is in registers: the doubles go where they were
+    DN_MG_TS(3);
+    const double rc = (double) rawc;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int r = w + W * k;                                             // wave-uniform; its tile row is k / (16 / W) whatever w is
+        constexpr int dummy = 0; (void) dummy;
+        const int rt = (W * k) >> 4;
+        // rows below p: offsets; row p: the plain row sums (cov_sums); rows beyond: as they are.  r is uniform: scalar selects
+        const double add_live = r < p ? fma(K, (double) rawr[k] + rc, nK2) : (r == p ? LK : 0.0);      // integers below 2^53: exact
+        const double v = (double) raw[k] + (col_live ? add_live : 0.0);
+        if (lane < R && ct <= rt) {                                          // the tiles on and below the diagonal were accumulated
+            g_mg[r * MG_LD + c] = v;
+            if (ct < rt) g_mg[c * MG_LD + r] = v;                            // mirror image: the solver walks whole rows
+        }
+    }
+    __syncthreads();
+}
+
 #ifndef DN_I8_ROWSEG
 #define DN_I8_ROWSEG 1          // 1: a load instruction reads 64 contiguous bytes per row (0: round 3's 64 contiguous bytes per LANE)
 #endif
@@ -847,7 +909,7 @@ constexpr int I8_LK = DN_I8_ROWSEG ? 4 : 16, I8_Q = DN_I8_ROWSEG ? 16 : 4;     /
 #endif
 
 template <int TR>
-__device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L, int p)
+DN_MG_FN void mg_gram_pass_i8(const float *x, int L, int p)
 {
     constexpr int NTILE = TR * (TR + 1) / 2;
     constexpr int W = NT / 64;
@@ -856,6 +918,10 @@ __device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L,
     dn_int4 hh[NTILE], ll[NTILE], hl[NTILE];
 #pragma unroll
     for (int i = 0; i < NTILE; i++) { hh[i] = dn_int4{0, 0, 0, 0}; ll[i] = hh[i]; hl[i] = hh[i]; }
+    // the matrix's place in LDS collects the waves' tiles as 64-bit integers first (below): zero it now, while nothing else is ready
+    long long *const g_mg64 = reinterpret_cast<long long *>(g_mg);
+    for (int idx = threadIdx.x; idx < 16 * TR * MG_LD; idx += NT) g_mg64[idx] = 0ll;
+    __syncthreads();
     gF_cptr rowp[TR];
     unsigned keep[TR], ones[TR];
 #pragma unroll
@@ -922,66 +988,80 @@ __device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L,
         for (; g + W < nfull; g += W) trip(std::true_type{}, g + W);
         trip(std::false_type{}, 0);
     }
-    if ((L & 63) && w == nfull % W) {                                        // the partial last group: columns beyond L are zero bytes
+    DN_MG_TS(0);
+    if ((L & 63) && w == nfull % W) {                                        // the partial last group
         dn_int4 H[TR], Lo[TR];
-        const int c = 64 * nfull + I8_LK * lk;
-#pragma unroll
-        for (int t = 0; t < TR; t++) {
+        if (L >= 64) {
+            // the LAST 64 columns of the gene in whole loads, the bytes of the columns the full groups have counted masked out (zero
+            // bytes add nothing to any of the sums): round 3 fetched every count of the group with a guarded load of its own, 10 k cycles
+            // during which the other three waves waited at the barrier
+            const int thr = 64 - (L & 63);                                   // columns thr .. 63 of the window are new
+            unsigned m[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                dn_f4 v;
-                unsigned m = 0;
+                const int d = thr - (I8_Q * q + I8_LK * lk);                 // elements d .. 3 of this lane's four are new
+                m[q] = d <= 0 ? 0xffffffffu : (d >= 4 ? 0u : (0xffffffffu << (8 * d)));
+            }
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int col = c + I8_Q * q + e;
-                    v[e] = col < L ? rowp[t][64 * nfull + I8_Q * q + e] : 0.0f;
-                    m |= col < L ? (0xffu << (8 * e)) : 0u;
+            for (int t = 0; t < TR; t++) {
+                dn_f4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = DN_P1_LOAD((gF4_cptr) (rowp[t] + (L - 64) + I8_Q * q));
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned lo, hi;
+                    pack4(v[q], lo, hi);
+                    Lo[t][q] = (int) (((lo & keep[t]) | ones[t]) & m[q]);
+                    H[t][q] = (int) (hi & keep[t] & m[q]);
                 }
-                unsigned lo, hi;
-                pack4(v, lo, hi);
-                Lo[t][q] = (int) (((lo & keep[t]) | ones[t]) & m);
-                H[t][q] = (int) (hi & keep[t] & m);
+            }
+        } else {                                                             // a gene shorter than one group: guarded element loads, columns beyond L are zero bytes
+            const int c = 64 * nfull + I8_LK * lk;
+#pragma unroll
+            for (int t = 0; t < TR; t++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    dn_f4 v;
+                    unsigned m = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int col = c + I8_Q * q + e;
+                        v[e] = col < L ? rowp[t][64 * nfull + I8_Q * q + e] : 0.0f;
+                        m |= col < L ? (0xffu << (8 * e)) : 0u;
+                    }
+                    unsigned lo, hi;
+                    pack4(v, lo, hi);
+                    Lo[t][q] = (int) (((lo & keep[t]) | ones[t]) & m);
+                    H[t][q] = (int) (hi & keep[t] & m);
+                }
             }
         }
         products(H, Lo);
     }
+    DN_MG_TS(1);
+    // Round 4: the waves' tiles are added up as 64-BIT INTEGERS in LDS (ds_add_u64, all four waves at once, any order: exact), then
+    // one pass turns every entry into its double, adds the offsets and writes the mirror image -- with all its LDS reads up front.
+    // Round 3 added the tiles in fp64 one wave after the other (four phases, a barrier each) and ran the offsets and the mirror as
+    // loops of one dependent LDS round trip per trip: 67 k cycles per gene between the last column and the solve, 24 % of a gene
+    // (stamps of the diagnostic build, profiles/round4/init_phases_*.txt).  Same numbers: sums of integers below 2^53.
     // tile (t1, t2): register r of lane (c = l & 15, q = l >> 4) holds entry [16 t1 + 4 q + r][16 t2 + c]
-    for (int ww = 0; ww < W; ww++) {
-        if (w == ww) {
-            int tix = 0;
+    {
+        int tix = 0;
 #pragma unroll
-            for (int t1 = 0; t1 < TR; t1++)
+        for (int t1 = 0; t1 < TR; t1++)
 #pragma unroll
-                for (int t2 = 0; t2 <= t1; t2++, tix++)
+            for (int t2 = 0; t2 <= t1; t2++, tix++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int row = 16 * t1 + 4 * lk + r, col = 16 * t2 + li;
-                        const double v = fma(65536.0, (double) hh[tix][r], fma(256.0, (double) hl[tix][r], (double) ll[tix][r]));
-                        if (ww == 0) g_mg[row * MG_LD + col] = v;
-                        else g_mg[row * MG_LD + col] += v;
-                    }
-        }
-        __syncthreads();
-    }
-    // offsets: r_i = 256 sum h'_i + sum l'_i sits in row p (the row of ones); x = 256 h' + l' + K
-    constexpr int R = 16 * TR;
-    constexpr double K = 32896.0;
-    const double nK2 = (double) L * K * K;
-    for (int idx = threadIdx.x; idx < R * R; idx += NT) {
-        const int r = idx / R, c = idx - r * R;
-        if (c <= r && r < p) {
-            const double ri = g_mg[p * MG_LD + r], rj = g_mg[p * MG_LD + c];
-            g_mg[r * MG_LD + c] += fma(K, ri + rj, nK2);                      // integers below 2^53: exact
-        }
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * t1 + 4 * lk + r, col = 16 * t2 + li;
+                    const long long v = 65536ll * (long long) hh[tix][r] + 256ll * (long long) hl[tix][r] + (long long) ll[tix][r];
+                    __hip_atomic_fetch_add(g_mg64 + row * MG_LD + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
     }
     __syncthreads();
-    if (threadIdx.x < p) g_mg[p * MG_LD + threadIdx.x] += (double) L * K;    // row p: the plain row sums (cov_sums)
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < R * R; idx += NT) {                    // mirror: the solver walks whole rows
-        const int r = idx / R, c = idx - r * R;
-        if (c > r) g_mg[r * MG_LD + c] = g_mg[c * MG_LD + r];
-    }
-    __syncthreads();
+    DN_MG_TS(2);
+    mg_finalize_i8<TR>(L, p);
+    DN_MG_TS(4);
 }
 
 // Top eigenvector of the p x p block of g_mg (p <= 64) by ONE wave: lane r keeps to row r of the matrix in LDS (row stride
@@ -990,7 +1070,7 @@ __device__ __attribute__((noinline)) void mg_gram_pass_i8(const float *x, int L,
 // this replaces paid two barriers per matrix-vector product plus two block reductions per check: 53 k cycles per gene for 7
 // steps).  Shifted power iteration, two plain steps between convergence checks, the stopping rule of top_eig_rows.  The other
 // waves wait at the closing barrier; with two workgroups per CU their SIMDs run the neighbour's passes meanwhile.
-__device__ __forceinline__ int mg_solve(int p, int maxs, double *u_out)
+__device__ __attribute__((noinline)) int mg_solve(int p, int maxs, double *u_out)
 {
     int status = ST_OK;
     if (wave_id() == 0) {
@@ -1079,7 +1159,7 @@ __device__ __forceinline__ int mg_solve(int p, int maxs, double *u_out)
 // (scalar block base + lane offset; the running 64-bit scalar base cost four scalar instructions per load); (iv) the block that
 // the gene's end leaves partial is done first, on its own, under the one exec mask it needs.
 template <int RC>                                                    // row capacity of this instantiation (p <= RC, p > RC - 8), a multiple of 8
-__device__ __attribute__((noinline)) void mg_pass2(const float *x_, int L, int p)
+DN_MG_FN void mg_pass2(const float *x_, int L, int p)
 {
     constexpr int W = NT / 64;
     const int tid = threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
@@ -1168,6 +1248,9 @@ __global__ __launch_bounds__(NT, 2) void k_ratio_svd_mg(InitArgs A)
     const int p = A.p;
     const int maxs = 5 * (A.max_steps > 0 ? A.max_steps : EIG_MAX_STEPS_DEFAULT);       // plain power steps, like top_singular
     const int TR = (p + 1 + 15) / 16;
+#ifdef DN_STAMP
+    long long ts_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         if (tid == 0) g_sm.gene = atomicAdd(A.counter, 1);
         __syncthreads();
@@ -1223,7 +1306,12 @@ __global__ __launch_bounds__(NT, 2) void k_ratio_svd_mg(InitArgs A)
             const long long ts3 = __builtin_amdgcn_s_memtime();
             A.est_sums[(size_t) g * p + 0] = (double) (ts1 - ts0); A.est_sums[(size_t) g * p + 1] = (double) (ts2 - ts1);
             A.est_sums[(size_t) g * p + 2] = (double) (ts3 - ts2); A.est_sums[(size_t) g * p + 3] = (double) g_st.steps;
+            // slots 4 .. 9: inside pass 1 (main loop, partial group, tile sums, offsets, mirror) and the time between the genes
+            A.est_sums[(size_t) g * p + 4] = (double) (g_mg_ts[0] - ts0);
+            for (int k = 1; k < 5; k++) A.est_sums[(size_t) g * p + 4 + k] = (double) (g_mg_ts[k] - g_mg_ts[k - 1]);
+            A.est_sums[(size_t) g * p + 9] = (double) (ts0 - ts_prev);
         }
+        ts_prev = __builtin_amdgcn_s_memtime();
 #endif
         __syncthreads();
     }

@@ -21,6 +21,12 @@ print('kernel %.2f ms for %d genes (%.2f GB): %.0f us per gene per workgroup at 
 print('cycles per gene (100 MHz s_memtime ticks x 24 = 2.4 GHz cycles): pass1 %.0f  solve %.0f  pass2 %.0f ; shares %.2f %.2f %.2f ; solver steps %.1f' % (
     c[:, 0].mean(), c[:, 1].mean(), c[:, 2].mean(), c[:, 0].sum() / tot, c[:, 1].sum() / tot, c[:, 2].sum() / tot, c[:, 3].mean()))
 print('sum of phase ticks / (512 workgroups) = %.2f ms at 100 MHz' % (tot / 512 / 1e5))
+if est.shape[1] >= 10:
+    names = ('pass 1 main loop', 'partial group', 'tile sums', 'offsets', 'mirror', 'between genes (results, queue, gene record)')
+    print('inside pass 1 and between the genes, cycles per gene: ' + '  '.join('%s %.0f' % (nm, est[:, 4 + k].mean()) for k, nm in enumerate(names)))
+    A = np.stack([np.ones(n), L], axis=1)
+    coef = np.linalg.lstsq(A, est[:, 4], rcond=None)[0]
+    print('pass 1 main loop ticks = %.0f + %.3f x L' % (coef[0], coef[1]))
 for name, col in (('pass1', 0), ('pass2', 2)):
     A = np.stack([np.ones(n), L], axis=1)
     coef = np.linalg.lstsq(A, c[:, col], rcond=None)[0]
