@@ -864,6 +864,8 @@ def test_integer_exact_gram_pass_vs_fp64_pass_and_oracle(oracle, monkeypatch, p)
     covs = [synth.synth_gene(77, g, p, 300, 3000)[0] for g in range(20)]
     covs.append(rng.poisson(30, size=(p, 37)).astype(float))                       # shorter than one 64-column group
     covs.append(rng.poisson(30, size=(p, 64)).astype(float))                       # exactly one group
+    for n_cols in (65, 127, 128, 129, 191, 2):                                     # one column into a group, one short of it, none: the partial group
+        covs.append(rng.poisson(30, size=(p, n_cols)).astype(float))               # re-reads the gene's last 64 columns and masks what was counted
     covs.append(np.vstack([np.zeros((1, 700)), rng.poisson(9, size=(p - 1, 700))]).astype(float))     # a zero sample
     big = rng.integers(60000, 65536, size=(p, 333)).astype(float)                  # at the 16-bit limit: offsets, no int32 overflow
     big[0, 0] = 65535.0
