@@ -1980,10 +1980,16 @@ __device__ __forceinline__ void nmf_body(const float *Fb_, double *Lg_, double *
             float xn[P];
             double an[P];
             if (cnt > 0) {
-                load_x<P>(Fb, k, xn);
+                // (the first column's index is opaque here: as a value fixed for the whole call the compiler keeps the addresses of its rows
+                // beyond the 4 095-byte reach of an immediate offset -- rows 8 and 9 at p = 10 -- in registers of their own, has no room
+                // for them next to the Gram accumulators and fetches each back from scratch in front of its load: reload, s_waitcnt
+                // vmcnt(0), load -- two memory round trips in a row at the head of every pass over a spill tier)
+                int kq = k;
+                asm volatile("" : "+v"(kq));
+                load_x<P>(Fb, kq, xn);
                 if (t > 0) {
 #pragma unroll
-                    for (int i = 0; i < P; i++) an[i] = *(spill_ptr<P>(Lg, k) + i * 64);
+                    for (int i = 0; i < P; i++) an[i] = *(spill_ptr<P>(Lg, kq) + i * 64);
                 }
             }
 #pragma clang loop unroll(disable)
