@@ -115,12 +115,12 @@ def launch_ranks(n, argv, launcher=None):
 # accounting helpers
 # ---------------------------------------------------------------------------------------------------------------------
 def source_hash():
-    """sha256 over the sources of the config-2 class kernels (the templates, the reduction, the instantiation unit) and the build
-    recipe with its flags: identifies the kernel code the PMC passes were taken on.  The host side (dn_api.hip) and the
-    run-time-p family are not part of it; what the host side decides -- which genes run in which class kernel -- is checked
-    separately (kernel names and gene counts of the profile against the run)."""
+    """sha256 over the kernel sources (the templates, the reduction, the generated DPP products, the instantiation unit of the class
+    kernels, the run-time-p family of config 4) and the build recipe with its flags: identifies the kernel code the PMC passes were
+    taken on.  The host side (dn_api.hip) is not part of it; what the host side decides -- which genes run in which class kernel --
+    is checked separately (kernel names and gene counts of the profile against the run)."""
     h = hashlib.sha256()
-    files = [os.path.join(ROOT, 'degnorm_amd', 'csrc', f) for f in ('dn_inst.hip', 'dn_kernels.hpp', 'dn_reduce.hpp')] + \
+    files = [os.path.join(ROOT, 'degnorm_amd', 'csrc', f) for f in ('dn_inst.hip', 'dn_kernels.hpp', 'dn_reduce.hpp', 'dn_dpp_ops.hpp', 'dn_generic.hip')] + \
             [os.path.join(ROOT, 'degnorm_amd', 'build.py')]
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -739,10 +739,11 @@ def measure(config, args, ctx, steps, warmup, n_parity, n_cpu, n_single, want_e2
         calls = float(np.mean([tr[:, 1].astype(np.float64).sum() for tr in all_traces]))
         solves = calls * (args.nmf_iter + 1)                                # nmf.py:90-101: T + 1 rank-one approximations per nmf() call
         steps_pw = float(np.mean([tr[:, 7].astype(np.float64).sum() for tr in all_traces]))
+        traffic4, tinfo4 = pmc_traffic(config, eng.dev.init_kernel_name(), n_genes) if (world == 1 and n_genes == cfg['n_genes']) else (None, {'refused': 'not the profiled shard'})
         out['roofline'] = {
             'bound': 'hbm', 'achieved': alg_init / (init_avg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': alg_init / (init_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'traffic': None,
-            'kernel': eng.dev.init_kernel_name(), 'avg_launch_ms': init_avg, 'launches_timed': len(init_ms),
+            'frac': alg_init / (init_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'traffic': traffic4, 'traffic_info': tinfo4,
+            'kernel': eng.dev.init_kernel_name(), 'genes_in_kernel': n_genes, 'avg_launch_ms': init_avg, 'launches_timed': len(init_ms),
             'algorithmic_bytes_per_launch': alg_init,
             'stream_read_ceiling_gbps': stream_gbps,
             'frac_of_stream_read_ceiling': (alg_init / (init_avg * 1e-3) / 1e9 / stream_gbps) if stream_gbps else None,

@@ -82,9 +82,11 @@ def main():
     for k in bench['roofline'].get('concurrent_kernels') or []:
         if k.get('kernel'):
             names.append((k['kernel'], k.get('genes')))
+    whole = (bench.get('config') or {}).get('genes_per_gpu')              # kernels that take every gene of the shard (config 4)
     for name, genes in names:
         if not name:
             continue
+        genes = whole if genes is None else genes
         rp = spaced(name) if '<' in name else name
         f_k, w_k = mean_of(fetch, rp), mean_of(write, rp)
         traffic['kernels'][name] = {
