@@ -851,7 +851,7 @@ def test_trace_columns_are_a_prefix_of_the_full_trace(device):
     device.set_trace_columns(_lib.TRACE_LEN)
 
 
-@pytest.mark.parametrize('p', [17, 33, 50, 63])
+@pytest.mark.parametrize('p', [17, 32, 33, 48, 50, 63])
 def test_integer_exact_gram_pass_vs_fp64_pass_and_oracle(oracle, monkeypatch, p):
     """
     The initial pass of wide cohorts forms the Gram matrix of whole-number counts EXACTLY on the i8 matrix cores (two bytes
