@@ -532,7 +532,6 @@ class ShardedNMFOA(object):
             self._trace_bufs[i] = trace
         self._record_kernel_times()
         self.traces.append(trace)
-        self._warn_unconverged(i, trace)
         self.scale_hist.append(np.copy(self.scale_factors))
         if self.history_rows is not None:
             rho_rows, flag_rows = self.dev.fetch_rows(self.history_rows)
@@ -546,6 +545,8 @@ class ShardedNMFOA(object):
             ptr, cnt = self.dev.outer_partials_device()               # the sums stay in HBM: the collective works on that buffer
             tot = self.comm.allreduce_device(ptr, cnt, self._dev_id)
         avg_di, norm = self._reduce_and_update(i, self.dev.outer_partials() if tot is None else None, tot)
+        if self.n_failed[-1][1] > 0:                                  # some rank's eigen-solve hit the step cap (counted in the all-reduce):
+            self._warn_unconverged(i, trace)                          # only then are this rank's counters searched for the genes' names
         self.dev.outer_apply(avg_di, norm, i)
         self._state_on_device = True
         self.rho = self.x_adj = None                                  # stale until fetch_state()
