@@ -92,7 +92,8 @@ int  dn_upload_packed(dn_handle h, int64_t n_genes, int32_t p, const float *pack
 /* Initialisation pass -------------------------------------------------------------------------------
  * Replaces: par_apply(run_ratio_svd_serial) + est_sums / cov_sums (nmf.py:522-525; nmf_mpi.py:681-703).
  * est_sums[g*p+i] = sum_j max(K_i E_j, x_ij), cov_sums[g*p+i] = sum_j x_ij on the raw coverage.
- * status[g] (nullable): 0 or the per-gene error code.                                                */
+ * status[g] (nullable): 0 or the per-gene error code (a gene of fewer than 2 columns: the reference's
+ * ValueError; for p >= 17 also a gene of more than 2^24 columns -- its rows are addressed by 32-bit offsets).      */
 int  dn_ratio_svd_sums(dn_handle h, double *est_sums, double *cov_sums, int32_t *status);
 
 /* One outer DegNorm iteration over all resident genes ------------------------------------------------
