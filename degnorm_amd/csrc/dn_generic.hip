@@ -699,7 +699,8 @@ __device__ __forceinline__ int top_singular_raw(const float *x, int L, int p)
 //           D[t1][t2] += X_t1(:, {c0 + m, c0 + 4 + m, c0 + 8 + m, c0 + 12 + m}) X_t2(...)^T.  The same register is the A
 //           and the B operand.  Row p of the padded matrix is a row of ones, so that G[p][i] = sum_j x_ij: the plain
 //           row sums (cov_sums) fall out of the same products.  Waves take 16-column groups round-robin; their tiles are
-//           added in LDS one wave after the other (fixed order: deterministic).
+//           added in LDS one wave after the other (fixed order: deterministic).  (Where every count fits 16 bits the Gram
+//           matrix is formed EXACTLY on the i8 matrix cores instead: mg_gram_pass_i8 below; this fp64 form serves the rest.)
 //   solve   top eigenvector of the p x p block by shifted power iteration, the matrix in LDS, ONE wave (lane = row, no barrier
 //           inside the iteration), two steps between convergence checks, the same stopping rule as top_eig_rows.
 //   pass 2  one column per lane: s_j = u . x_j from the p counts of the column (registers), per-lane partial sums of
@@ -840,9 +841,10 @@ __device__ __forceinline__ void mg_gram_pass(const float *x, int L, int p)
 // fp64 pass which columns share an instruction does not matter, so load q = 0..3 of lane (i = l & 15, kb = l >> 4) takes the four
 // counts c0 + 16 q + 4 kb .. + 3 of row 16 t + i: the four lanes of a row read 64 CONTIGUOUS bytes per load instruction (one whole
 // sector per row and instruction; the per-lane-contiguous form of round 3 touched 64 sectors for a quarter each), a row's 256 bytes
-// per wave in four instructions, and the same registers serve as A and as B operand.  Row p is a row of ones in l' (zeros in h'): r_j falls out of the same products.  Every wave takes
-// 64-column groups round-robin; a wave's int32 tiles hold at most 2 x 16 384 x (L / 4) -- genes longer than 2^17 bases take
-// the fp64 pass.  The tiles are combined in fp64 (sums of integers below 2^53: exact) into g_mg like the fp64 pass's.
+// per wave in four instructions, and the same registers serve as A and as B operand.  Row p is a row of ones in l' (zeros in h'):
+// r_j falls out of the same products.  Every wave takes 64-column groups round-robin; a wave's int32 tiles hold at most
+// 2 x 16 384 x (L / 4) -- genes longer than 2^17 bases take the fp64 pass.  The waves' tiles are added up as 64-bit integers in
+// LDS (ds_add_u64, any order: exact) where the matrix goes, and mg_finalize_i8 turns the sums into the fp64 matrix (round 4).
 // ---------------------------------------------------------------------------------------------------
 typedef int dn_int4 __attribute__((ext_vector_type(4)));
 
