@@ -292,3 +292,23 @@ def test_generated_dpp_ops_header_is_current(tmp_path):
     for p in (2, 10, 16):
         assert 'dpp_matvec<%d>' % p in committed and 'dpp_rowdot<%d>' % p in committed
     assert committed.count('row_newbcast:15') == 2                      # only p = 16 reaches the last lane of a row
+
+
+def test_integration_md_c_loop_compiles_against_the_header(tmp_path):
+    """The C-only sharded loop INTEGRATION.md shows (dn_comm_* / dn_init_allreduce / dn_outer_allreduce) is checked against
+    include/degnorm_amd.h by the C compiler: names, argument counts and pointer types (-fsyntax-only, no GPU, nothing is run)."""
+    import re
+    import subprocess
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = [b for b in re.findall(r'```c\n(.*?)```', text, flags=re.S) if 'dn_comm_create' in b]
+    assert len(blocks) == 1
+    src = tmp_path / 'loop.c'
+    src.write_text('#include <stdint.h>\n#include <stddef.h>\n#include "degnorm_amd.h"\n#define P_MAX 64\n'
+                   'void bcast(void *buf, size_t bytes, int root);\n'
+                   'void sharded_loop(int local_gpu, int r, int R, int64_t n_r, int32_t p, const float *my_packed_f32, const int64_t *my_lengths,\n'
+                   '                  const double *my_reads, double *norm, double *scale, double *avg_di, int32_t degnorm_iter, dn_params prm,\n'
+                   '                  int32_t *trace, double *rho, double *x_adj, double *x_weighted, uint8_t *ran)\n{\n' + blocks[0] + '}\n')
+    r = subprocess.run(['gcc', '-std=c99', '-fsyntax-only', '-Wall', '-Werror=implicit-function-declaration', '-Werror=incompatible-pointer-types',
+                        '-Werror=int-conversion', '-I', os.path.join(ROOT, 'include'), str(src)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       universal_newlines=True)
+    assert r.returncode == 0, r.stdout
