@@ -312,3 +312,16 @@ def test_integration_md_c_loop_compiles_against_the_header(tmp_path):
                         '-Werror=int-conversion', '-I', os.path.join(ROOT, 'include'), str(src)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        universal_newlines=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_integration_md_ctypes_stub_parses_and_names_exist():
+    """The abridged ctypes binding in INTEGRATION.md is valid Python and every dn_* entry point it calls is declared in the header."""
+    import ast
+    import re
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = [b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'ctypes.CDLL' in b]
+    assert len(blocks) == 1
+    ast.parse(blocks[0])
+    header = open(os.path.join(ROOT, 'include', 'degnorm_amd.h')).read()
+    for name in set(re.findall(r'lib\.(dn_\w+)', blocks[0])):
+        assert re.search(r'\b' + name + r'\s*\(', header), name
